@@ -1,0 +1,97 @@
+"""ctypes binding of ``libcryovit_hip.so`` (the C ABI in ``include/cryovit_hip.h``).
+
+The product path has no fallback: if the library is missing or a call fails, this raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libcryovit_hip.so"
+
+EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT = range(7)
+
+c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("epilogue", c_int),
+        ("a", c_void_p), ("lda", c_long),
+        ("w", c_void_p), ("ldw", c_long),
+        ("m", c_long), ("n", c_long), ("n_pad", c_long), ("k_pad", c_long),
+        ("out", c_void_p), ("ldc", c_long),
+        ("bias", c_void_p),
+        ("gamma", c_void_p),
+        ("pos", c_void_p), ("ldpos", c_long),
+        ("npatch", c_int), ("ntp", c_int), ("tok0", c_int),
+        ("heads", c_int), ("kp", c_int),
+        ("H", c_int), ("W", c_int), ("cout", c_int), ("act", c_int),
+    ]
+
+
+class Conv3dDesc(C.Structure):
+    _fields_ = [
+        ("in_", c_void_p), ("w", c_void_p), ("bias", c_void_p), ("zero_page", c_void_p), ("out", c_void_p),
+        ("C", c_int), ("D", c_int), ("H", c_int), ("W", c_int), ("dil", c_int), ("cout", c_int),
+        ("n_pad", c_int), ("k_pad", c_int), ("act", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/cryovit_hip.h declares
+SIGNATURES = {
+    "cvx_last_error": (C.c_char_p, []),
+    "cvx_version": (c_int, []),
+    "cvx_device_arch": (c_int, [C.c_char_p, c_int]),
+    "cvx_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
+    "cvx_conv3d_bf16": (c_int, [C.POINTER(Conv3dDesc), c_void_p]),
+    "cvx_layernorm_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
+    "cvx_attention_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cvx_preprocess_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "cvx_init_tokens": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cvx_final_norm_features": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),
+    "cvx_im2col_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "cvx_features_to_channels_last": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
+    "cvx_groupnorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
+    "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_void_p]),
+    "cvx_dice_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+class CvxError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and bind every declared symbol; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise CvxError(
+            f"{LIB_PATH} not found: build it with `python -m cryovit_amd.build` (hipcc, gfx950). "
+            "cryovit_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().cvx_last_error().decode(errors="replace")
+        raise CvxError(f"{what} failed ({rc}): {msg}")
+
+
+def device_arch() -> str:
+    buf = C.create_string_buffer(128)
+    check(load().cvx_device_arch(buf, 128), "cvx_device_arch")
+    return buf.value.decode()

@@ -1,0 +1,179 @@
+// Flash-style multi-head attention for the ViT blocks, head_dim 64, gfx950.
+//
+// One workgroup = 4 waves = 128 query rows of one (slice, head); each wave owns 32 query rows.
+// Per 64-key tile:   S^T = K Q^T  (v_mfma_f32_32x32x16_bf16, "swapped" so a query row sits on ONE lane and
+// the softmax row reductions are lane-local + one cross-half exchange), online softmax in fp32, then
+// O^T += V^T P^T where the S^T accumulator registers are converted in place into the B operand (no LDS
+// round trip for P).  K rows are read through the permutation pi (swap bits 2,3 of the row index) so
+// that the k order the accumulator-as-operand trick imposes becomes 8 CONTIGUOUS keys of V^T -- which the
+// QKV GEMM epilogue writes transposed (CVX_EPI_VT), so V^T fragments are plain ds_read_b128.
+// K and V^T tiles are double-buffered in LDS by LDS-DMA (global_load_lds_dwordx4), one barrier per tile,
+// XOR-swizzled on the source address (conflict-free ds_read_b128).
+#include "common.h"
+#include "../../include/cryovit_hip.h"
+#include "host_util.h"
+
+namespace cvx {
+
+constexpr int ATT_THREADS = 256;
+constexpr int KV_TILE = 64;
+constexpr int ATT_TILE_BYTES = 64 * 128;  // 64 rows x 64 bf16
+
+__device__ __forceinline__ int pi_row(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+__global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __restrict__ qk, long ldqk,
+                                                           const uint16_t* __restrict__ vt, uint16_t* __restrict__ out,
+                                                           long ldo, int heads, int ntok, int ntp, int kp, int C) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * ATT_TILE_BYTES];  // [buf][K | V^T]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slice = blockIdx.z, head = blockIdx.y;
+    const long row0 = (long)slice * ntp;
+    const uint16_t* Qp = qk + row0 * ldqk + head * 64;
+    const uint16_t* Kp = Qp + C;
+    const uint16_t* Vp = vt + ((long)(slice * heads + head) * 64) * kp;
+
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = min(q0 + r, ntp - 1);  // rows past the slice are clamped for loads, never stored
+
+    // Q fragments: B operand of S^T = K Q^T.  lane (r,h) holds Q[q0+r][16*ks + 8*h + j]
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qp + (long)qrow * ldqk + 16 * ks + 8 * h);
+
+    // LDS-DMA source offsets for this thread's two 16-B pieces of each tile
+    int srow[2], schunk[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int c = jj * ATT_THREADS + tid;
+        srow[jj] = c >> 3;
+        schunk[jj] = ((c & 7) ^ ((srow[jj] >> 1) & 7)) << 3;
+    }
+    auto issue = [&](int j, int buf) {
+        char* kt = smem + buf * 2 * ATT_TILE_BYTES;
+        char* vtile = kt + ATT_TILE_BYTES;
+        const long kv0 = (long)j * KV_TILE;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            glds16(Kp + (kv0 + srow[jj]) * ldqk + schunk[jj], kt + (jj * ATT_THREADS + wave * 64) * 16);
+            glds16(Vp + (long)srow[jj] * kp + kv0 + schunk[jj], vtile + (jj * ATT_THREADS + wave * 64) * 16);
+        }
+    };
+
+    // fragment read offsets
+    const int krow = pi_row(r);
+    const int koff = krow * 128, ksw = (krow >> 1) & 7;  // K tile: row 32t + pi(r), 16-B chunk 2*ks + h
+    const int voff = r * 128, vsw = (r >> 1) & 7;        // V^T tile: row 32dt + r, chunk 4t + 2s + h
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float LOG2E = 1.4426950408889634f;
+
+    const int nkv = (ntok + KV_TILE - 1) / KV_TILE;
+    issue(0, 0);
+    for (int j = 0; j < nkv; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile j landed; every wave is done with tile j-1
+        if (j + 1 < nkv) issue(j + 1, (j + 1) & 1);
+        const char* kt = smem + (j & 1) * 2 * ATT_TILE_BYTES;
+        const char* vtile = kt + ATT_TILE_BYTES;
+
+        // ---- S^T[t] = K_t Q^T : rows = keys (registers), col = query (lane) ----
+        f32x16 s[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kt + t * 4096 + koff + (((2 * ks + h) ^ ksw) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+
+        // ---- mask keys >= ntok (last tile only; wave-uniform test) ----
+        const int kv0 = j * KV_TILE;
+        if (kv0 + KV_TILE > ntok) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (kv0 + 32 * t + pi_row(rho) >= ntok) s[t][i] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (scores already carry head_dim^-0.5 through Q) ----
+        float mloc = s[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, s[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, s[1][i]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        const float mb = m_new * LOG2E;
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[t][i], LOG2E, -mb));
+                s[t][i] = p;
+                psum += p;
+            }
+        l_run = fmaf(l_run, alpha, psum);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+
+        // ---- O^T[dt] += V^T[dt] P^T : accumulator registers 8s..8s+7 of S^T[t] are k-step s of the B operand ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[t][8 * sk + e];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 vf = *(const bf16x8*)(vtile + dt * 4096 + voff + (((4 * t + 2 * sk + h) ^ vsw) << 4));
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+    }
+
+    // ---- normalise and store: lane (r,h) holds O[q0+r][32dt + 8g + 4h + (0..3)] in regs 4g..4g+3 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q0 + r < ntok) {
+        uint16_t* orow = out + (row0 + q0 + r) * ldo + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+                w.y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+                *(uint2*)(orow + 32 * dt + 8 * g + 4 * h) = w;
+            }
+    }
+}
+
+}  // namespace cvx
+
+using namespace cvx;
+
+extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
+                                  int ntok, int ntp, int kp, hipStream_t st) {
+    if (slices <= 0) return 0;
+    if (ntp % 8 || kp % 64 || kp < ntok || ntp < ntok || ldqk % 8 || ldo % 4)
+        return cvx_fail("attention: need ntp%8==0, kp%64==0, kp>=ntok, ntp>=ntok, ldqk%8==0");
+    if (heads > 65535 || slices > 65535) return cvx_fail("attention: heads/slices exceed grid limits");
+    dim3 grid((ntok + 127) / 128, heads, slices);
+    hipLaunchKernelGGL(k_attention, grid, dim3(ATT_THREADS), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt,
+                       (uint16_t*)out, ldo, heads, ntok, ntp, kp, heads * 64);
+    return cvx_check_launch();
+}

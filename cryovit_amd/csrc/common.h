@@ -1,0 +1,59 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the CryoVIT hot path.
+// Wave = 64 lanes everywhere; bf16 storage, fp32 accumulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cvx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CVX_GLOBAL_AS __attribute__((address_space(1)))
+#define CVX_LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// branch-free erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7): keeps fused epilogues straight-line
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-ax * ax);
+    const float r = fmaf(-p * t, e, 1.0f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const CVX_GLOBAL_AS void*)gsrc, (CVX_LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace cvx

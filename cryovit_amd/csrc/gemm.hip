@@ -1,0 +1,349 @@
+// Dense / implicit-GEMM launchers and fused epilogues (gfx950).  See gemm_core.h for the tile kernel.
+#include "gemm_core.h"
+#include "../../include/cryovit_hip.h"
+#include "host_util.h"
+
+namespace cvx {
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  NREG orientation: store<NV>(n0, m, v) -- v[i] is output feature n0+i of row m.
+//             MREG orientation: store<NV>(m0, n, v) -- v[i] is row m0+i of output feature n.
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void store_bf16_chunked(uint16_t* dst, const float* v, long n0, long n_valid) {
+    if constexpr (NV >= 8) {
+#pragma unroll
+        for (int h = 0; h < NV / 8; ++h) {
+            if (n0 + h * 8 < n_valid) {
+                uint4 w;
+                w.x = pack2bf(v[h * 8 + 0], v[h * 8 + 1]);
+                w.y = pack2bf(v[h * 8 + 2], v[h * 8 + 3]);
+                w.z = pack2bf(v[h * 8 + 4], v[h * 8 + 5]);
+                w.w = pack2bf(v[h * 8 + 6], v[h * 8 + 7]);
+                *(uint4*)(dst + h * 8) = w;
+            }
+        }
+    } else {
+        static_assert(NV == 4, "NV must be 4 or a multiple of 8");
+        if (n0 < n_valid) {
+            uint2 w;
+            w.x = pack2bf(v[0], v[1]);
+            w.y = pack2bf(v[2], v[3]);
+            *(uint2*)dst = w;
+        }
+    }
+}
+
+template <int NV>
+struct VecCtx {
+    float bias[NV];
+    float gamma[NV];
+};
+template <int NV>
+__device__ __forceinline__ void load_vec(float* dst, const float* src) {
+#pragma unroll
+    for (int h = 0; h < NV / 4; ++h) {
+        const float4 t = *(const float4*)(src + h * 4);
+        dst[h * 4 + 0] = t.x; dst[h * 4 + 1] = t.y; dst[h * 4 + 2] = t.z; dst[h * 4 + 3] = t.w;
+    }
+}
+
+// out[m][n] = bf16(act(acc + bias[n]));  ACT: 0 none, 1 GELU(erf)
+template <int ACT>
+struct EpiBF16 {
+    uint16_t* out; long ldc; const float* bias; long m_valid, n_valid;
+    template <int NV> using Ctx = VecCtx<NV>;
+    template <int NV>
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const { load_vec<NV>(c.bias, bias + n0); }
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+        if (m >= m_valid) return;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float t = acc[i] + c.bias[i];
+            v[i] = ACT == 1 ? gelu_erf(t) : t;
+        }
+        store_bf16_chunked<NV>(out + m * ldc + n0, v, n0, n_valid);
+    }
+};
+
+// SwiGLU gate: packed W12 rows are interleaved in blocks of 8 (a[8j..8j+7], b[8j..8j+7]) so a lane's 16
+// contiguous accumulators are 8 a's and the 8 matching b's:  out[m][n0/2 + i] = silu(a_i) * b_i
+struct EpiSwiGLU {
+    uint16_t* out; long ldc; const float* bias; long m_valid, n_valid;
+    template <int NV> using Ctx = VecCtx<NV>;
+    template <int NV>
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const { load_vec<NV>(c.bias, bias + n0); }
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+        static_assert(NV == 16, "SwiGLU epilogue needs 16 contiguous features per lane");
+        if (m >= m_valid || n0 >= n_valid) return;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = silu(acc[i] + c.bias[i]) * (acc[8 + i] + c.bias[8 + i]);
+        store_bf16_chunked<8>(out + m * ldc + (n0 >> 1), v, 0, 1);
+    }
+};
+
+// residual stream update in fp32:  x[m][n] += gamma[n] * (acc + bias[n])
+struct EpiResid {
+    float* x; long ldx; const float* bias; const float* gamma; long m_valid, n_valid;
+    template <int NV> using Ctx = VecCtx<NV>;
+    template <int NV>
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const {
+        load_vec<NV>(c.bias, bias + n0);
+        load_vec<NV>(c.gamma, gamma + n0);
+    }
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+        if (m >= m_valid) return;
+#pragma unroll
+        for (int h = 0; h < NV / 4; ++h) {
+            const long n = n0 + h * 4;
+            if (n >= n_valid) continue;
+            float4 xv = *(float4*)(x + m * ldx + n);
+            xv.x += c.gamma[h * 4 + 0] * (acc[h * 4 + 0] + c.bias[h * 4 + 0]);
+            xv.y += c.gamma[h * 4 + 1] * (acc[h * 4 + 1] + c.bias[h * 4 + 1]);
+            xv.z += c.gamma[h * 4 + 2] * (acc[h * 4 + 2] + c.bias[h * 4 + 2]);
+            xv.w += c.gamma[h * 4 + 3] * (acc[h * 4 + 3] + c.bias[h * 4 + 3]);
+            *(float4*)(x + m * ldx + n) = xv;
+        }
+    }
+};
+
+// patch embedding: GEMM row m = slice*npatch + p  ->  token row slice*ntp + tok0 + p of the fp32 stream,
+// value = acc + bias[n] + pos[(1+p)][n]
+struct EpiPatch {
+    float* x; long ldx; const float* bias; const float* pos; long ldpos; int npatch, ntp, tok0; long m_valid, n_valid;
+    template <int NV> using Ctx = VecCtx<NV>;
+    template <int NV>
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const { load_vec<NV>(c.bias, bias + n0); }
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+        if (m >= m_valid) return;
+        const long s = m / npatch, p = m - s * npatch;
+        float* dst = x + (s * ntp + tok0 + p) * ldx;
+        const float* pp = pos + (1 + p) * ldpos;
+#pragma unroll
+        for (int h = 0; h < NV / 4; ++h) {
+            const long n = n0 + h * 4;
+            if (n >= n_valid) continue;
+            const float4 q = *(const float4*)(pp + n);
+            float4 o;
+            o.x = acc[h * 4 + 0] + c.bias[h * 4 + 0] + q.x;
+            o.y = acc[h * 4 + 1] + c.bias[h * 4 + 1] + q.y;
+            o.z = acc[h * 4 + 2] + c.bias[h * 4 + 2] + q.z;
+            o.w = acc[h * 4 + 3] + c.bias[h * 4 + 3] + q.w;
+            *(float4*)(dst + n) = o;
+        }
+    }
+};
+
+// V written TRANSPOSED for the attention kernel (MREG orientation: a lane owns NV consecutive tokens of one
+// feature n = head*64 + d):   vt[slice][head][d][t] = acc + bias[n],   token row m = slice*ntp + t
+struct EpiVT {
+    uint16_t* vt; const float* bias; int heads, ntp, kp; long m_valid, n_valid;
+    template <int NV> struct Ctx {};
+    template <int NV>
+    __device__ __forceinline__ void prep(Ctx<NV>&, long) const {}
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>&, long m0, long n, const float* acc) const {
+        static_assert(NV % 8 == 0, "V^T epilogue stores 8 tokens (16 B) at a time");
+        if (n >= n_valid) return;
+        const float b = bias[n];
+        const long head = n >> 6, d = n & 63;
+#pragma unroll
+        for (int h = 0; h < NV / 8; ++h) {
+            const long m8 = m0 + h * 8;
+            if (m8 >= m_valid) continue;
+            const long s = m8 / ntp, t = m8 - s * ntp;  // ntp % 8 == 0: a group of 8 never straddles slices
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = acc[h * 8 + i] + b;
+            store_bf16_chunked<8>(vt + ((s * heads + head) * 64 + d) * (long)kp + t, v, 0, 1);
+        }
+    }
+};
+
+// ConvTranspose3d kernel=stride=(1,2,2) as a GEMM with N = 4*Cout (n = (i*2+j)*Cout + o), pixel-shuffle
+// scatter into the channels-last output [D][2H][2W][Cout], GELU fused.  bias is pre-expanded to N entries.
+template <int ACT>
+struct EpiConvT {
+    uint16_t* out; const float* bias; int H, W, cout; long m_valid, n_valid;
+    template <int NV> using Ctx = VecCtx<NV>;
+    template <int NV>
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const { load_vec<NV>(c.bias, bias + n0); }
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+        if (m >= m_valid) return;
+        const long xq = m % W, t = m / W, yq = t % H, zq = t / H;
+        constexpr int CH = NV >= 8 ? 8 : 4;
+#pragma unroll
+        for (int h = 0; h < NV / CH; ++h) {
+            const long n = n0 + h * CH;
+            if (n >= n_valid) continue;
+            const int ij = (int)(n / cout), o = (int)(n - (long)ij * cout);
+            float v[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float tt = acc[h * CH + i] + c.bias[h * CH + i];
+                v[i] = ACT == 1 ? gelu_erf(tt) : tt;
+            }
+            uint16_t* dst = out + ((zq * (2L * H) + 2 * yq + (ij >> 1)) * (2L * W) + 2 * xq + (ij & 1)) * cout + o;
+            store_bf16_chunked<CH>(dst, v, 0, 1);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
+                                                             int nk, int tiles_n, int tiles_m, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tr, tl;
+    tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
+    PlainLoader<Cfg::BR, Cfg::FRG> ldr;
+    PlainLoader<Cfg::BL, 0> ldl;
+    ldr.init(Wt, ldw, (long)tr * Cfg::BR, threadIdx.x);
+    ldl.init(A, lda, (long)tl * Cfg::BL, threadIdx.x);
+    gemm_tile_body<Cfg>(ldr, ldl, epi, nk, (long)tr * Cfg::BR, (long)tl * Cfg::BL, smem);
+}
+
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_mreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
+                                                             int nk, int tiles_n, int tiles_m, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tr, tl;
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tr, tl);
+    PlainLoader<Cfg::BR, Cfg::FRG> ldr;
+    PlainLoader<Cfg::BL, 0> ldl;
+    ldr.init(A, lda, (long)tr * Cfg::BR, threadIdx.x);
+    ldl.init(Wt, ldw, (long)tl * Cfg::BL, threadIdx.x);
+    gemm_tile_body<Cfg>(ldr, ldl, epi, nk, (long)tr * Cfg::BR, (long)tl * Cfg::BL, smem);
+}
+
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(GEMM_THREADS) void k_conv3_nreg(const uint16_t* in, const uint16_t* zero, int C, int D, int H,
+                                                              int W, int dil, const uint16_t* Wt, long ldw, int nk,
+                                                              int tiles_n, int tiles_m, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tr, tl;
+    tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
+    PlainLoader<Cfg::BR, Cfg::FRG> ldr;
+    Conv3Loader<Cfg::BL> ldl;
+    ldr.init(Wt, ldw, (long)tr * Cfg::BR, threadIdx.x);
+    ldl.init(in, zero, C, D, H, W, dil, (long)tl * Cfg::BL, (long)D * H * W, threadIdx.x);
+    gemm_tile_body<Cfg>(ldr, ldl, epi, nk, (long)tr * Cfg::BR, (long)tl * Cfg::BL, smem);
+}
+
+template <class Cfg, class Epi>
+static int launch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad,
+                       const Epi& epi, hipStream_t st) {
+    const int tiles_n = (int)(Npad / Cfg::BR), tiles_m = (int)((M + Cfg::BL - 1) / Cfg::BL);
+    auto k = k_gemm_nreg<Cfg, Epi>;
+    CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, A, lda, Wt, ldw,
+                       (int)(Kpad / BK), tiles_n, tiles_m, epi);
+    return cvx_check_launch();
+}
+
+template <class Epi>
+static int dispatch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad,
+                         const Epi& epi, hipStream_t st) {
+    if (Kpad % BK) return cvx_fail("gemm: K must be padded to a multiple of 64");
+    if (Npad % 128 == 0) return launch_nreg<TileCfg<128, 128, 2>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+    if (Npad % 64 == 0) return launch_nreg<TileCfg<64, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+    if (Npad % 32 == 0) return launch_nreg<TileCfg<32, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+    if (Npad % 16 == 0) return launch_nreg<TileCfg<16, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+    return cvx_fail("gemm: N must be padded to a multiple of 16");
+}
+
+template <class Cfg, class Epi>
+static int launch_conv3(const cvx_conv3d_desc& d, const Epi& epi, hipStream_t st) {
+    const long M = (long)d.D * d.H * d.W;
+    const int tiles_n = (int)(d.n_pad / Cfg::BR), tiles_m = (int)((M + Cfg::BL - 1) / Cfg::BL);
+    auto k = k_conv3_nreg<Cfg, Epi>;
+    CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, (const uint16_t*)d.in,
+                       (const uint16_t*)d.zero_page, d.C, d.D, d.H, d.W, d.dil, (const uint16_t*)d.w, (long)d.k_pad,
+                       (int)(d.k_pad / BK), tiles_n, tiles_m, epi);
+    return cvx_check_launch();
+}
+
+}  // namespace cvx
+
+using namespace cvx;
+
+extern "C" int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t st) {
+    if (!d) return cvx_fail("gemm: null descriptor");
+    const uint16_t* A = (const uint16_t*)d->a;
+    const uint16_t* W = (const uint16_t*)d->w;
+    if (d->m <= 0) return 0;
+    switch (d->epilogue) {
+        case CVX_EPI_BF16: {
+            EpiBF16<0> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
+            return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
+        case CVX_EPI_BF16_GELU: {
+            EpiBF16<1> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
+            return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
+        case CVX_EPI_SWIGLU: {
+            if (d->n_pad % 128) return cvx_fail("gemm: SwiGLU needs N padded to 128");
+            EpiSwiGLU e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
+            return launch_nreg<TileCfg<128, 128, 2>>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
+        case CVX_EPI_RESID: {
+            EpiResid e{(float*)d->out, d->ldc, d->bias, d->gamma, d->m, d->n};
+            return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
+        case CVX_EPI_PATCH: {
+            EpiPatch e{(float*)d->out, d->ldc, d->bias, d->pos, d->ldpos, d->npatch, d->ntp, d->tok0, d->m, d->n};
+            return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
+        case CVX_EPI_VT: {
+            if (d->n_pad % 128 || d->k_pad % BK) return cvx_fail("gemm: V^T epilogue needs N padded to 128, K to 64");
+            EpiVT e{(uint16_t*)d->out, d->bias, d->heads, d->ntp, d->kp, d->m, d->n};
+            using Cfg = TileCfg<128, 128, 2>;
+            const int tiles_n = (int)(d->n_pad / Cfg::BL), tiles_m = (int)((d->m + Cfg::BR - 1) / Cfg::BR);
+            auto k = k_gemm_mreg<Cfg, EpiVT>;
+            CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+            hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, A, d->lda, W, d->ldw,
+                               (int)(d->k_pad / BK), tiles_n, tiles_m, e);
+            return cvx_check_launch();
+        }
+        case CVX_EPI_CONVT: {
+            if (d->cout % 8) return cvx_fail("gemm: ConvT C_out must be a multiple of 8");
+            if (d->act) {
+                EpiConvT<1> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+                return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            }
+            EpiConvT<0> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+            return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
+        default:
+            return cvx_fail("gemm: unknown epilogue");
+    }
+}
+
+template <int ACT>
+static int conv3_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
+    const long M = (long)d.D * d.H * d.W;
+    EpiBF16<ACT> e{(uint16_t*)d.out, (long)d.cout, d.bias, M, (long)d.cout};
+    if (d.n_pad % 128 == 0) return launch_conv3<TileCfg<128, 128, 2>>(d, e, st);
+    if (d.n_pad % 64 == 0) return launch_conv3<TileCfg<64, 256, 1>>(d, e, st);
+    if (d.n_pad % 32 == 0) return launch_conv3<TileCfg<32, 256, 1>>(d, e, st);
+    if (d.n_pad % 16 == 0) return launch_conv3<TileCfg<16, 256, 1>>(d, e, st);
+    return cvx_fail("conv3d: C_out must be padded to a multiple of 16");
+}
+
+extern "C" int cvx_conv3d_bf16(const cvx_conv3d_desc* d, hipStream_t st) {
+    if (!d) return cvx_fail("conv3d: null descriptor");
+    if (d->C % 8) return cvx_fail("conv3d: C_in must be a multiple of 8");
+    if (d->k_pad % BK || d->k_pad < 27 * d->C) return cvx_fail("conv3d: K must be 27*C_in padded to a multiple of 64");
+    if (d->cout % 4) return cvx_fail("conv3d: C_out must be a multiple of 4");
+    return d->act ? conv3_dispatch<1>(*d, st) : conv3_dispatch<0>(*d, st);
+}

@@ -1,0 +1,219 @@
+// bf16 MFMA tile GEMM core for gfx950:  T[r][l] = sum_k R[r][k] * L[l][k]   (both operands K-contiguous)
+//
+// One kernel template serves every dense contraction on the hot path (ViT linears, patch embed,
+// the head's 1x1x1 / dilated 3x3x3 / transposed convolutions as implicit GEMMs).
+//
+//   * "R side": the operand whose row index lands in the MFMA accumulator REGISTERS
+//     (v_mfma_f32_16x16x32_bf16 A operand), "L side": the operand whose row index lands on LANES.
+//     NREG orientation: R = weights [N][K], L = activations [M][K]  -> each lane owns 4*FR CONTIGUOUS
+//     output features of one activation row -> 16/32-byte row-major stores, 128-B lines per row.
+//     MREG orientation: R = activations, L = weights -> each lane owns contiguous ROWS of one feature
+//     (used to write V transposed for the attention kernel).
+//   * LDS tiles are [rows][64] bf16 (128-B rows), filled by global_load_lds_dwordx4 (LDS-DMA, no VGPR
+//     round trip).  The DMA destination is lane-linear, so the bank swizzle (16-B chunk ^= (row>>1)&7,
+//     conflict-free for ds_read_b128 over 16 consecutive rows) and the R-side row permutation sigma
+//     (which makes a lane's accumulator registers contiguous in the output) are both applied to the
+//     per-lane SOURCE address; reads apply the same XOR.
+//   * K loop: double-buffered, one barrier per 64-deep K tile (next tile's DMA issued before the MFMAs).
+#pragma once
+#include "common.h"
+
+namespace cvx {
+
+constexpr int BK = 64;
+constexpr int GEMM_THREADS = 256;
+
+__device__ __forceinline__ int swz_chunk(int row) { return (row >> 1) & 7; }
+
+// LDS row -> source row inside a group of 16*FRG rows: lane group g=(i>>2) ends up holding source rows
+// [g*4*FRG, (g+1)*4*FRG) of the group, ordered (frag, reg).
+template <int FRG>
+__device__ __forceinline__ int sigma_row(int lds_row) {
+    if constexpr (FRG == 0) {
+        return lds_row;
+    } else {
+        constexpr int G = 16 * FRG;
+        const int grp = lds_row / G, in = lds_row % G;
+        const int f = in >> 4, i = in & 15;
+        return grp * G + (i >> 2) * (4 * FRG) + 4 * f + (i & 3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile loaders.  issue(lds_tile, kt) starts the LDS-DMA of K tile kt into lds_tile ([ROWS][64] bf16).
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, int FRG>
+struct PlainLoader {
+    static constexpr int NJ = (ROWS * 8 + GEMM_THREADS - 1) / GEMM_THREADS;
+    const uint16_t* base;  // tile origin: matrix + row0*ld
+    uint32_t off[NJ];      // per-thread element offsets (row*ld + chunk*8)
+    int wave;
+
+    __device__ __forceinline__ void init(const uint16_t* mat, long ld, long row0, int tid) {
+        base = mat + row0 * ld;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = j * GEMM_THREADS + tid;
+            const int row = c >> 3, pos = c & 7;
+            off[j] = (uint32_t)(sigma_row<FRG>(row) * ld + ((pos ^ swz_chunk(row)) << 3));
+        }
+    }
+    __device__ __forceinline__ void issue(char* lds_tile, int kt) const {
+        const uint16_t* b = base + kt * BK;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if ((ROWS * 8) % GEMM_THREADS != 0 && (j * GEMM_THREADS + wave * 64) >= ROWS * 8) break;
+            glds16(b + off[j], lds_tile + (j * GEMM_THREADS + wave * 64) * 16);
+        }
+    }
+};
+
+// Implicit-GEMM gather for a 3x3x3 convolution with dilation (dil,1,1), zero "same" padding, over a
+// channels-last volume in[D][H][W][C] (bf16).  Row = output voxel, K index = tap*C + c (tap = (kz*3+ky)*3+kx).
+// Out-of-volume taps and K padding read from a zero page.
+template <int ROWS>
+struct Conv3Loader {
+    static constexpr int NJ = (ROWS * 8 + GEMM_THREADS - 1) / GEMM_THREADS;
+    const uint16_t* in;
+    const uint16_t* zero;
+    int C, D, H, W, dil;
+    int z[NJ], y[NJ], x[NJ];
+    int chunk[NJ];  // source 16-B chunk within the 64-wide K tile (swizzle folded in)
+    bool rowok[NJ];
+    int wave;
+
+    __device__ __forceinline__ void init(const uint16_t* in_, const uint16_t* zero_, int C_, int D_, int H_, int W_,
+                                         int dil_, long row0, long nvox, int tid) {
+        in = in_; zero = zero_; C = C_; D = D_; H = H_; W = W_; dil = dil_;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = j * GEMM_THREADS + tid;
+            const int row = c >> 3, pos = c & 7;
+            chunk[j] = pos ^ swz_chunk(row);
+            long v = row0 + row;
+            rowok[j] = v < nvox;
+            if (!rowok[j]) v = 0;
+            x[j] = (int)(v % W);
+            const long t = v / W;
+            y[j] = (int)(t % H);
+            z[j] = (int)(t / H);
+        }
+    }
+    __device__ __forceinline__ void issue(char* lds_tile, int kt) const {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if ((ROWS * 8) % GEMM_THREADS != 0 && (j * GEMM_THREADS + wave * 64) >= ROWS * 8) break;
+            const int kk = kt * BK + chunk[j] * 8;
+            const int tap = kk / C, c = kk - tap * C;
+            const int kz = tap / 9, r9 = tap - kz * 9, ky = r9 / 3, kx = r9 - ky * 3;
+            const int zz = z[j] + (kz - 1) * dil, yy = y[j] + ky - 1, xx = x[j] + kx - 1;
+            const bool ok = rowok[j] && tap < 27 && (unsigned)zz < (unsigned)D && (unsigned)yy < (unsigned)H &&
+                            (unsigned)xx < (unsigned)W;
+            const uint16_t* g = ok ? in + (((long)zz * H + yy) * W + xx) * C + c : zero;
+            glds16(g, lds_tile + (j * GEMM_THREADS + wave * 64) * 16);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Kernel
+// ------------------------------------------------------------------------------------------------
+template <int BR_, int BL_, int WAVES_R_>
+struct TileCfg {
+    static constexpr int BR = BR_, BL = BL_, WAVES_R = WAVES_R_, WAVES_L = 4 / WAVES_R_;
+    static constexpr int WR = BR / WAVES_R, WL = BL / WAVES_L;
+    static constexpr int FR = WR / 16, FL = WL / 16;
+    static constexpr int FRG = FR > 4 ? 4 : FR;  // sigma group = min(wave tile, 64) rows
+    static constexpr int TILE_R_BYTES = BR * 128, TILE_L_BYTES = BL * 128;
+    static constexpr int STAGE_BYTES = TILE_R_BYTES + TILE_L_BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static_assert(WR % 16 == 0 && WL % 16 == 0, "wave tile must be a multiple of 16");
+    static_assert(FR <= 4 || FR % 4 == 0, "R wave tile > 64 must be a multiple of 64");
+};
+
+// XCD-aware, grouped tile order: blocks b and b+8 share an XCD (private L2), so each XCD gets a contiguous
+// chunk of the logical tile sequence (bijective for any grid size); inside the sequence, tiles sweep the
+// R dimension within bands of GROUP_L L-tiles so concurrently resident blocks share operand panels.
+__device__ __forceinline__ void tile_coords(int bid, int nblk, int tiles_r, int tiles_l, int& tr, int& tl) {
+    const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7;
+    const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    constexpr int GROUP_L = 8;
+    const int per_band = GROUP_L * tiles_r;
+    const int band = id / per_band, in = id - band * per_band;
+    const int l_first = band * GROUP_L;
+    const int gl = min(GROUP_L, tiles_l - l_first);
+    tl = l_first + in % gl;
+    tr = in / gl;
+}
+
+template <class Cfg, class LoaderR, class LoaderL, class Epi>
+__device__ __forceinline__ void gemm_tile_body(const LoaderR& ldr, const LoaderL& ldl, const Epi& epi, int nk,
+                                               long r0, long l0, char* smem) {
+    constexpr int FR = Cfg::FR, FL = Cfg::FL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr0 = (wave / Cfg::WAVES_L) * Cfg::WR, wl0 = (wave % Cfg::WAVES_L) * Cfg::WL;
+
+    f32x4 acc[FR][FL];
+#pragma unroll
+    for (int a = 0; a < FR; ++a)
+#pragma unroll
+        for (int b = 0; b < FL; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment read offsets (k-step 0); k-step 1 is the same offset ^ 64
+    const int sw = (lane & 15) >> 1;
+    const int fo = (lane & 15) * 128 + (((lane >> 4) ^ sw) << 4);
+    const int offR = wr0 * 128 + fo;
+    const int offL = Cfg::TILE_R_BYTES + wl0 * 128 + fo;
+
+    ldr.issue(smem, 0);
+    ldl.issue(smem + Cfg::TILE_R_BYTES, 0);
+    __syncthreads();  // hipcc drains vmcnt(0) here: the LDS-DMA has landed
+
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
+        if (kt + 1 < nk) {
+            char* nxt = smem + ((kt + 1) & 1) * Cfg::STAGE_BYTES;
+            ldr.issue(nxt, kt + 1);
+            ldl.issue(nxt + Cfg::TILE_R_BYTES, kt + 1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 rf[FR], lf[FL];
+#pragma unroll
+            for (int a = 0; a < FR; ++a) rf[a] = *(const bf16x8*)(cur + ((offR + a * 2048) ^ (ks << 6)));
+#pragma unroll
+            for (int b = 0; b < FL; ++b) lf[b] = *(const bf16x8*)(cur + ((offL + b * 2048) ^ (ks << 6)));
+#pragma unroll
+            for (int a = 0; a < FR; ++a)
+#pragma unroll
+                for (int b = 0; b < FL; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[a], lf[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+    }
+
+    // epilogue: lane (g = lane>>4) owns R rows [g*4*FRG, +4*FRG) of each 16*FRG-row group, one L row per frag
+    constexpr int FRG = Cfg::FRG, NG = FR / FRG;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+        const long rbase = r0 + wr0 + grp * 16 * FRG + g * 4 * FRG;
+        typename Epi::template Ctx<4 * FRG> ctx;
+        epi.template prep<4 * FRG>(ctx, rbase);  // per-R constants (bias, gamma) loaded once per lane
+#pragma unroll
+        for (int b = 0; b < FL; ++b) {
+            const long l = l0 + wl0 + b * 16 + (lane & 15);
+            float v[4 * FRG];
+#pragma unroll
+            for (int f = 0; f < FRG; ++f)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[grp * FRG + f][b][e];
+            epi.template store<4 * FRG>(ctx, rbase, l, v);
+        }
+    }
+}
+
+}  // namespace cvx

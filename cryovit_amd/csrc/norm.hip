@@ -1,0 +1,283 @@
+// Normalisation and layout kernels (HBM-bound): LayerNorm fp32 -> bf16, final LayerNorm + feature layouts,
+// GroupNorm over channels-last bf16 volumes, fp16 [C][D][h][w] -> bf16 channels-last.
+#include "common.h"
+#include "../../include/cryovit_hip.h"
+#include "host_util.h"
+
+namespace cvx {
+
+constexpr int LN_MAXJ = 8;  // float4 per lane: C <= 64*4*8 = 2048
+
+// One wave per row; the row lives in registers (two-pass mean / centred variance, fp32).
+__device__ __forceinline__ void ln_row_stats(const float* row, int C4, int lane, float4 (&v)[LN_MAXJ], float& mean,
+                                             float& rstd, int C, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int i = lane + 64 * j;
+        if (i < C4) {
+            v[j] = *(const float4*)(row + 4 * i);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+    }
+    mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int i = lane + 64 * j;
+        if (i < C4) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+}
+
+__global__ __launch_bounds__(256) void k_layernorm_bf16(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, uint16_t* __restrict__ out, long ldo,
+                                                        long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C4 = C >> 2;
+    float4 v[LN_MAXJ];
+    float mean, rstd;
+    ln_row_stats(x + row * ldx, C4, lane, v, mean, rstd, C, eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ; ++j) {
+        const int i = lane + 64 * j;
+        if (i < C4) {
+            const float4 ww = *(const float4*)(w + 4 * i), bb = *(const float4*)(b + 4 * i);
+            uint2 o;
+            o.x = pack2bf((v[j].x - mean) * rstd * ww.x + bb.x, (v[j].y - mean) * rstd * ww.y + bb.y);
+            o.y = pack2bf((v[j].z - mean) * rstd * ww.z + bb.z, (v[j].w - mean) * rstd * ww.w + bb.w);
+            *(uint2*)(out + row * ldo + 4 * i) = o;
+        }
+    }
+}
+
+// Final LayerNorm of the patch tokens of `slices` slices, written as
+//   feats_cl  bf16 [slice][p][C]                 (row-major, for the head)
+//   feats_f16 fp16 [C][d_total][npatch] at depth d0+slice   (the reference's `dino_features` layout)
+// A workgroup owns 64 consecutive patch tokens of one slice; the fp16 transposition goes through an LDS tile
+// [256 channels][64 tokens] so global stores are 128-B runs along the token axis.
+constexpr int FN_TOK = 64, FN_CH = 256, FN_PITCH = FN_TOK + 8;  // pitch in halfwords (144 B, 16-B aligned)
+
+__global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                    const float* __restrict__ b, float eps, int ntp, int tok0, int npatch,
+                                                    int C, _Float16* __restrict__ f16, long d_total, long d0,
+                                                    uint16_t* __restrict__ cl, float* __restrict__ f32) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[FN_CH * FN_PITCH];
+    __shared__ float s_mean[FN_TOK], s_rstd[FN_TOK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.y, p0 = blockIdx.x * FN_TOK;
+    const int ntile = min(FN_TOK, npatch - p0);
+    const int C4 = C >> 2;
+    const float* xs = x + ((long)slice * ntp + tok0 + p0) * ldx;
+
+    // phase 1: statistics (and the channels-last bf16 copy) -- one wave per token, 16 tokens per wave
+    for (int t = wave; t < ntile; t += 4) {
+        float4 v[LN_MAXJ];
+        float mean, rstd;
+        ln_row_stats(xs + (long)t * ldx, C4, lane, v, mean, rstd, C, eps);
+        if (lane == 0) { s_mean[t] = mean; s_rstd[t] = rstd; }
+        if (f32) {  // x_norm_patchtokens [slice][p][C] in fp32 (the encoder-protocol output)
+            float* orow = f32 + ((long)slice * npatch + p0 + t) * C;
+#pragma unroll
+            for (int j = 0; j < LN_MAXJ; ++j) {
+                const int i = lane + 64 * j;
+                if (i < C4) {
+                    const float4 ww = *(const float4*)(w + 4 * i), bb = *(const float4*)(b + 4 * i);
+                    float4 o;
+                    o.x = (v[j].x - mean) * rstd * ww.x + bb.x; o.y = (v[j].y - mean) * rstd * ww.y + bb.y;
+                    o.z = (v[j].z - mean) * rstd * ww.z + bb.z; o.w = (v[j].w - mean) * rstd * ww.w + bb.w;
+                    *(float4*)(orow + 4 * i) = o;
+                }
+            }
+        }
+        if (cl) {
+            uint16_t* orow = cl + ((long)slice * npatch + p0 + t) * C;
+#pragma unroll
+            for (int j = 0; j < LN_MAXJ; ++j) {
+                const int i = lane + 64 * j;
+                if (i < C4) {
+                    const float4 ww = *(const float4*)(w + 4 * i), bb = *(const float4*)(b + 4 * i);
+                    uint2 o;
+                    o.x = pack2bf((v[j].x - mean) * rstd * ww.x + bb.x, (v[j].y - mean) * rstd * ww.y + bb.y);
+                    o.y = pack2bf((v[j].z - mean) * rstd * ww.z + bb.z, (v[j].w - mean) * rstd * ww.w + bb.w);
+                    *(uint2*)(orow + 4 * i) = o;
+                }
+            }
+        }
+    }
+    if (!f16) return;
+    __syncthreads();
+
+    // phase 2: fp16 [C][depth][token] through the LDS transpose tile, 256 channels at a time
+    for (int c0 = 0; c0 < C; c0 += FN_CH) {
+        const int nch = min(FN_CH, C - c0);
+        // thread -> channel (tid), loop tokens: global reads are 256 consecutive floats per token (coalesced)
+        if (tid < nch) {
+            const float ww = w[c0 + tid], bb = b[c0 + tid];
+            for (int t = 0; t < ntile; ++t) {
+                const float val = (xs[(long)t * ldx + c0 + tid] - s_mean[t]) * s_rstd[t] * ww + bb;
+                tile[tid * FN_PITCH + t] = (_Float16)val;
+            }
+        }
+        __syncthreads();
+        // thread -> (channel row, 16-B piece of 8 tokens)
+        for (int idx = tid; idx < nch * (FN_TOK / 8); idx += 256) {
+            const int c = idx >> 3, piece = idx & 7;
+            _Float16* dst = f16 + ((long)(c0 + c) * d_total + d0 + slice) * npatch + p0 + piece * 8;
+            const _Float16* src = tile + c * FN_PITCH + piece * 8;
+            if (piece * 8 + 8 <= ntile && (((uintptr_t)dst) & 15) == 0) {
+                *(uint4*)dst = *(const uint4*)src;
+            } else {
+                for (int e = 0; e < 8; ++e)
+                    if (piece * 8 + e < ntile) dst[e] = src[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// fp16 [C][nvox] -> bf16 [nvox][C]   (HDF5 `dino_features` -> head input), 64x64 LDS transpose tiles
+__global__ __launch_bounds__(256) void k_f16_to_cl(const _Float16* __restrict__ in, uint16_t* __restrict__ out, int C,
+                                                   long nvox) {
+    __shared__ float tile[64][65];
+    const long v0 = (long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i;
+        const long v = v0 + tx;
+        tile[i][tx] = (c < C && v < nvox) ? (float)in[(long)c * nvox + v] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const long v = v0 + i;
+        const int c = c0 + tx;
+        if (v < nvox && c < C) out[v * C + c] = f2bf(tile[tx][i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm over x[nvox][C] bf16 (channels-last), G groups of C/G adjacent channels.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x, float* __restrict__ stats, long nvox, int C,
+                                                  int G, long vox_per_block) {
+    extern __shared__ float red[];  // [2*C]
+    const int tid = threadIdx.x;
+    const int cpt = C >> 3;         // 16-B chunks per voxel (power of two <= 256)
+    const int cc = tid % cpt, vsub = tid / cpt, vstride = 256 / cpt;
+    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    const long v0 = (long)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+    for (long v = v0 + vsub; v < v1; v += vstride) {
+        const uint4 u = *(const uint4*)(x + v * C + cc * 8);
+        const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bflo(wds[e]), b = bfhi(wds[e]);
+            s[2 * e] += a; q[2 * e] += a * a;
+            s[2 * e + 1] += b; q[2 * e + 1] += b * b;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(&red[cc * 8 + e], s[e]);
+        atomicAdd(&red[C + cc * 8 + e], q[e]);
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        float ss = 0.f, qq = 0.f;
+        for (int e = 0; e < cpg; ++e) { ss += red[g * cpg + e]; qq += red[C + g * cpg + e]; }
+        atomicAdd(&stats[g], ss);
+        atomicAdd(&stats[G + g], qq);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x, const float* __restrict__ stats,
+                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                  uint16_t* __restrict__ out, long nvox, int C, int G, float eps,
+                                                  long vox_per_block) {
+    const int tid = threadIdx.x;
+    const int cpt = C >> 3;
+    const int cc = tid % cpt, vsub = tid / cpt, vstride = 256 / cpt;
+    const int cpg = C / G;
+    const double cnt = (double)nvox * cpg;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cc * 8 + e, g = c / cpg;
+        const double mean = (double)stats[g] / cnt;
+        double var = (double)stats[G + g] / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        sc[e] = rstd * w[c];
+        sh[e] = b[c] - (float)mean * sc[e];
+    }
+    const long v0 = (long)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+    for (long v = v0 + vsub; v < v1; v += vstride) {
+        const uint4 u = *(const uint4*)(x + v * C + cc * 8);
+        uint4 o;
+        o.x = pack2bf(fmaf(bflo(u.x), sc[0], sh[0]), fmaf(bfhi(u.x), sc[1], sh[1]));
+        o.y = pack2bf(fmaf(bflo(u.y), sc[2], sh[2]), fmaf(bfhi(u.y), sc[3], sh[3]));
+        o.z = pack2bf(fmaf(bflo(u.z), sc[4], sh[4]), fmaf(bfhi(u.z), sc[5], sh[5]));
+        o.w = pack2bf(fmaf(bflo(u.w), sc[6], sh[6]), fmaf(bfhi(u.w), sc[7], sh[7]));
+        *(uint4*)(out + v * C + cc * 8) = o;
+    }
+}
+
+}  // namespace cvx
+
+using namespace cvx;
+
+extern "C" int cvx_layernorm_bf16(const float* x, long ldx, const float* w, const float* b, void* out, long ldo,
+                                  long rows, int C, float eps, hipStream_t st) {
+    if (rows <= 0) return 0;
+    if (C % 4 || C > 64 * 4 * LN_MAXJ || ldx % 4 || ldo % 4) return cvx_fail("layernorm: C%4==0, C<=2048, ld%4==0 required");
+    hipLaunchKernelGGL(k_layernorm_bf16, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, w, b, (uint16_t*)out,
+                       ldo, rows, C, eps);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_final_norm_features(const float* x, long ldx, const float* w, const float* b, float eps, int slices,
+                                       int ntp, int tok0, int hp, int wp, int C, void* feats_f16, long d_total, long d0,
+                                       void* feats_cl, float* tokens_f32, hipStream_t st) {
+    if (slices <= 0) return 0;
+    if (C % 4 || C > 64 * 4 * LN_MAXJ || ldx % 4) return cvx_fail("final_norm: C%4==0, C<=2048, ldx%4==0 required");
+    const int npatch = hp * wp;
+    dim3 grid((npatch + FN_TOK - 1) / FN_TOK, slices);
+    hipLaunchKernelGGL(k_final_norm, grid, dim3(256), 0, st, x, ldx, w, b, eps, ntp, tok0, npatch, C, (_Float16*)feats_f16,
+                       d_total, d0, (uint16_t*)feats_cl, tokens_f32);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_features_to_channels_last(const void* feats_f16, void* out_cl, int C, long nvox, hipStream_t st) {
+    if (nvox <= 0) return 0;
+    dim3 grid((unsigned)((nvox + 63) / 64), (C + 63) / 64);
+    hipLaunchKernelGGL(k_f16_to_cl, grid, dim3(256), 0, st, (const _Float16*)feats_f16, (uint16_t*)out_cl, C, nvox);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_groupnorm_bf16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
+                                  int G, float eps, hipStream_t st) {
+    if (nvox <= 0) return 0;
+    const int cpt = C / 8;
+    if (C % 8 || cpt > 256 || (cpt & (cpt - 1)) || C % G) return cvx_fail("groupnorm: C must be 8*2^k <= 2048 and divisible by G");
+    CVX_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * G, st));
+    const long vox_per_block = 2048;
+    const unsigned nblk = (unsigned)((nvox + vox_per_block - 1) / vox_per_block);
+    hipLaunchKernelGGL(k_gn_stats, dim3(nblk), dim3(256), sizeof(float) * 2 * C, st, (const uint16_t*)x, stats, nvox, C, G,
+                       vox_per_block);
+    int rc = cvx_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gn_apply, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, stats, w, b, (uint16_t*)out, nvox, C, G,
+                       eps, vox_per_block);
+    return cvx_check_launch();
+}

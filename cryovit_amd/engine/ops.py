@@ -1,0 +1,138 @@
+"""Thin torch-tensor wrappers over the C ABI (``include/cryovit_hip.h``).
+
+torch is plumbing here: it owns device memory and the HIP stream; every arithmetic op below is a call into
+``libcryovit_hip.so``.  All wrappers launch on ``torch.cuda.current_stream()``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from cryovit_amd import _lib
+from cryovit_amd._lib import Conv3dDesc, GemmDesc, check
+
+ROW_PAD = 256  # activation matrices are allocated to a multiple of this many rows (+ one spare tile)
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def alloc_rows(m: int) -> int:
+    return round_up(m, ROW_PAD) + ROW_PAD
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _dev_check(*ts) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CvxError("cryovit_amd ops need device (HIP) tensors; there is no CPU path")
+
+
+def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, *, m: int, n: int,
+         gamma=None, pos=None, npatch=0, ntp=0, tok0=0, heads=0, kp=0, H=0, W=0, cout=0, act=0, ldc=None) -> None:
+    """C = A W^T with a fused epilogue.  a: bf16 [M_alloc, lda]; w: bf16 [n_pad, k_pad] (packed)."""
+    _dev_check(a, w, out, bias, gamma, pos)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and bias.dtype == torch.float32
+    assert a.stride(-1) == 1 and w.is_contiguous() and bias.numel() >= w.shape[0]
+    d = GemmDesc()
+    d.epilogue = epilogue
+    d.a, d.lda = a.data_ptr(), a.stride(0)
+    d.w, d.ldw = w.data_ptr(), w.stride(0)
+    d.m, d.n, d.n_pad, d.k_pad = m, n, w.shape[0], w.shape[1]
+    d.out = out.data_ptr()
+    d.ldc = ldc if ldc is not None else (out.stride(0) if out.dim() >= 2 else 0)
+    d.bias, d.gamma = bias.data_ptr(), _p(gamma)
+    d.pos, d.ldpos = _p(pos), (pos.stride(0) if pos is not None else 0)
+    d.npatch, d.ntp, d.tok0, d.heads, d.kp = npatch, ntp, tok0, heads, kp
+    d.H, d.W, d.cout, d.act = H, W, cout, act
+    check(_lib.load().cvx_gemm_bf16(C.byref(d), _stream()), "cvx_gemm_bf16")
+
+
+def conv3d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, zero_page: torch.Tensor, *, Cin: int,
+           D: int, H: int, W: int, dil: int, cout: int, act: int) -> None:
+    _dev_check(x, w, bias, out, zero_page)
+    d = Conv3dDesc()
+    d.in_, d.w, d.bias, d.zero_page, d.out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), zero_page.data_ptr(), out.data_ptr()
+    d.C, d.D, d.H, d.W, d.dil, d.cout = Cin, D, H, W, dil, cout
+    d.n_pad, d.k_pad, d.act = w.shape[0], w.shape[1], act
+    check(_lib.load().cvx_conv3d_bf16(C.byref(d), _stream()), "cvx_conv3d_bf16")
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, rows: int, Cdim: int, eps: float) -> None:
+    _dev_check(x, w, b, out)
+    check(_lib.load().cvx_layernorm_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), out.data_ptr(), out.stride(0),
+                                         rows, Cdim, eps, _stream()), "cvx_layernorm_bf16")
+
+
+def attention(qk: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, slices: int, heads: int, ntok: int, ntp: int,
+              kp: int) -> None:
+    _dev_check(qk, vt, out)
+    check(_lib.load().cvx_attention_bf16(qk.data_ptr(), qk.stride(0), vt.data_ptr(), out.data_ptr(), out.stride(0), slices,
+                                         heads, ntok, ntp, kp, _stream()), "cvx_attention_bf16")
+
+
+def preprocess_patches(slices: torch.Tensor, out: torch.Tensor) -> None:
+    _dev_check(slices, out)
+    assert slices.dim() == 3 and slices.is_contiguous() and slices.dtype in (torch.uint8, torch.float32)
+    b, H, W = slices.shape
+    check(_lib.load().cvx_preprocess_patches(slices.data_ptr(), int(slices.dtype == torch.uint8), b, H, W, out.data_ptr(),
+                                             out.stride(0), _stream()), "cvx_preprocess_patches")
+
+
+def init_tokens(x: torch.Tensor, cls_pos0: torch.Tensor, reg: torch.Tensor, *, n_reg: int, slices: int, ntok: int, ntp: int,
+                Cdim: int) -> None:
+    _dev_check(x, cls_pos0, reg)
+    check(_lib.load().cvx_init_tokens(x.data_ptr(), x.stride(0), cls_pos0.data_ptr(), reg.data_ptr(), n_reg, slices, ntok, ntp,
+                                      Cdim, _stream()), "cvx_init_tokens")
+
+
+def final_norm_features(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, *, slices: int, ntp: int, tok0: int,
+                        hp: int, wp: int, Cdim: int, feats_f16, d_total: int, d0: int, feats_cl, tokens_f32=None) -> None:
+    _dev_check(x, w, b, feats_f16, feats_cl, tokens_f32)
+    check(_lib.load().cvx_final_norm_features(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), eps, slices, ntp, tok0, hp,
+                                              wp, Cdim, _p(feats_f16), d_total, d0, _p(feats_cl), _p(tokens_f32), _stream()),
+          "cvx_final_norm_features")
+
+
+def im2col_patches(x: torch.Tensor, out: torch.Tensor) -> None:
+    _dev_check(x, out)
+    assert x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32 and x.is_contiguous()
+    b, _, Hi, Wi = x.shape
+    check(_lib.load().cvx_im2col_patches(x.data_ptr(), b, Hi, Wi, out.data_ptr(), out.stride(0), _stream()), "cvx_im2col_patches")
+
+
+def features_to_channels_last(feats_f16: torch.Tensor, out_cl: torch.Tensor) -> None:
+    _dev_check(feats_f16, out_cl)
+    Cdim = feats_f16.shape[0]
+    nvox = feats_f16.numel() // Cdim
+    check(_lib.load().cvx_features_to_channels_last(feats_f16.data_ptr(), out_cl.data_ptr(), Cdim, nvox, _stream()),
+          "cvx_features_to_channels_last")
+
+
+def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, stats: torch.Tensor, *, nvox: int,
+              Cdim: int, G: int, eps: float) -> None:
+    _dev_check(x, w, b, out, stats)
+    check(_lib.load().cvx_groupnorm_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(), nvox, Cdim,
+                                         G, eps, _stream()), "cvx_groupnorm_bf16")
+
+
+def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs, labels, dice, *, D: int, H: int, W: int) -> None:
+    _dev_check(x, w, logits, probs, labels, dice)
+    check(_lib.load().cvx_conv3_out_fused(x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), _p(labels), _p(dice), D,
+                                          H, W, _stream()), "cvx_conv3_out_fused")
+
+
+def dice_sums(probs: torch.Tensor, labels: torch.Tensor, dice: torch.Tensor, thr: float = 0.5) -> None:
+    _dev_check(probs, labels, dice)
+    check(_lib.load().cvx_dice_sums(probs.data_ptr(), labels.data_ptr(), dice.data_ptr(), probs.numel(), thr, _stream()),
+          "cvx_dice_sums")

@@ -1,0 +1,260 @@
+"""DINOv2-with-registers encoder on the HIP kernels: weight packing + the per-batch launch sequence.
+
+Replaces what the reference delegates to the third-party hub model at
+``/root/reference/src/cryovit/run/dino_features.py:58`` (``forward_features``) together with the host-side
+resize of ``/root/reference/src/cryovit/datasets/vit_dataset.py:117-123`` and the reshape/permute/half of
+``run/dino_features.py:59-61``.  Algorithm: SURVEY.md App. A.
+
+Data layout in HBM (b slices, C channels, NT = hp*wp+1+n_reg tokens, NTP = NT rounded up to 8):
+  x      fp32 [b*NTP (+pad)][C]   residual stream (row = slice*NTP + token; rows NT..NTP-1 are finite padding)
+  xn     bf16 [..][C]             LayerNorm output = GEMM A operand
+  qk     bf16 [..][2C]            Q (pre-scaled by head_dim^-0.5) | K, token-major
+  vt     bf16 [b][heads][64][KP]  V transposed per head (KP = NT rounded up to 64), written by the V GEMM epilogue
+  ao     bf16 [..][C]             attention output
+  hid    bf16 [..][Hd_pad]        gated / activated FFN hidden
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU, EPI_PATCH, EPI_RESID, EPI_SWIGLU, EPI_VT
+from cryovit_amd.engine import ops
+from cryovit_amd.engine.ops import alloc_rows, round_up
+
+
+@dataclass(frozen=True)
+class VitConfig:
+    dim: int
+    depth: int
+    heads: int
+    ffn: str  # "swiglu" | "mlp"
+    ffn_hidden: int
+    n_reg: int = 4
+    patch: int = 14
+    pos_grid: int = 37
+    ln_eps: float = 1e-6
+
+    def __post_init__(self):
+        if self.dim // self.heads != 64 or self.dim % self.heads:
+            raise ValueError("the HIP attention kernel is specialised for head_dim 64 (every DINOv2 variant)")
+        if self.patch != 14:
+            raise ValueError("patch size must be 14")
+
+
+def _swiglu_hidden(dim: int) -> int:
+    return (int(dim * 4 * 2 / 3) + 7) // 8 * 8
+
+
+VIT_CONFIGS = {
+    # the model the reference hard-codes (run/dino_features.py:25-28)
+    "dinov2_vitg14_reg": VitConfig(1536, 40, 24, "swiglu", _swiglu_hidden(1536)),
+    "dinov2_vitl14_reg": VitConfig(1024, 24, 16, "mlp", 4096),
+    "dinov2_vitb14_reg": VitConfig(768, 12, 12, "mlp", 3072),
+    "dinov2_vits14_reg": VitConfig(384, 12, 6, "mlp", 1536),
+}
+
+
+def _bf16_padded(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
+    out = torch.zeros(n_pad, k_pad, dtype=torch.bfloat16)
+    out[: w.shape[0], : w.shape[1]] = w.to(torch.bfloat16)
+    return out
+
+
+def _f32_padded(v: torch.Tensor, n_pad: int) -> torch.Tensor:
+    out = torch.zeros(n_pad, dtype=torch.float32)
+    out[: v.numel()] = v.float().reshape(-1)
+    return out
+
+
+def interpolate_pos_embed(cfg: VitConfig, pos_embed: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
+    """[1,1+G*G,C] -> fp32 [1+hp*wp, C]; bicubic + antialias (App. A-2).  Weight-only, once per (hp, wp)."""
+    G = cfg.pos_grid
+    pe = pos_embed.float()
+    if hp == G and wp == G:
+        return pe[0].contiguous()
+    patch = pe[:, 1:].reshape(1, G, G, cfg.dim).permute(0, 3, 1, 2)
+    patch = F.interpolate(patch, size=(hp, wp), mode="bicubic", align_corners=False, antialias=True)
+    patch = patch.permute(0, 2, 3, 1).reshape(hp * wp, cfg.dim)
+    return torch.cat([pe[0, :1], patch], dim=0).contiguous()
+
+
+class VitEngine:
+    """Holds packed device weights and per-shape workspaces; ``features()`` runs one slice batch."""
+
+    def __init__(self, cfg: VitConfig, state_dict: dict, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise ops._lib.CvxError("VitEngine needs a HIP device (no CPU fallback)")
+        ops._lib.load()
+        self.cfg, self.device = cfg, torch.device(device)
+        self._pos_src = state_dict["pos_embed"].detach().float().cpu()
+        self._cls = state_dict["cls_token"].detach().float().cpu().reshape(-1)
+        self._ws = {}
+        self._pos = {}
+        self._pack(state_dict)
+
+    # ---- weight packing (host, once) -----------------------------------------------------------------------------
+    def _pack(self, sd: dict) -> None:
+        cfg, dev = self.cfg, self.device
+        C = cfg.dim
+        n128 = round_up(C, 128)
+
+        def up(t):
+            return t.contiguous().to(dev)
+
+        g = lambda k: sd[k].detach().float().cpu()  # noqa: E731
+        w = {}
+        # patch embed: the three input channels are identical copies (vit_dataset.py:117-118) -> sum the kernel
+        # over channels (exact in real arithmetic), K = 196 padded to 256
+        pe = g("patch_embed.proj.weight").sum(dim=1).reshape(C, 196)
+        w["pe_w"] = up(_bf16_padded(pe, n128, 256))
+        w["pe_b"] = up(_f32_padded(g("patch_embed.proj.bias"), n128))
+        # general 3-channel kernel for the protocol entry point forward_features(x): K = 588 padded to 640
+        w["pe3_w"] = up(_bf16_padded(g("patch_embed.proj.weight").reshape(C, 588), n128, 640))
+        w["reg"] = up(g("register_tokens").reshape(cfg.n_reg, C))
+        w["norm_w"], w["norm_b"] = up(g("norm.weight")), up(g("norm.bias"))
+        self.hid_pad = round_up(cfg.ffn_hidden, 64)
+        blocks = []
+        scale = 64**-0.5  # exact power of two: folding it into bf16 weights is lossless
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            qkv_w, qkv_b = g(p + "attn.qkv.weight").clone(), g(p + "attn.qkv.bias").clone()
+            qkv_w[:C] *= scale
+            qkv_b[:C] *= scale
+            blk = {
+                "ln1_w": up(g(p + "norm1.weight")), "ln1_b": up(g(p + "norm1.bias")),
+                "qk_w": up(_bf16_padded(qkv_w[: 2 * C], round_up(2 * C, 128), C)),
+                "qk_b": up(_f32_padded(qkv_b[: 2 * C], round_up(2 * C, 128))),
+                "v_w": up(_bf16_padded(qkv_w[2 * C :], n128, C)),
+                "v_b": up(_f32_padded(qkv_b[2 * C :], n128)),
+                "proj_w": up(_bf16_padded(g(p + "attn.proj.weight"), n128, C)),
+                "proj_b": up(_f32_padded(g(p + "attn.proj.bias"), n128)),
+                "ls1": up(_f32_padded(g(p + "ls1.gamma"), n128)),
+                "ln2_w": up(g(p + "norm2.weight")), "ln2_b": up(g(p + "norm2.bias")),
+                "ls2": up(_f32_padded(g(p + "ls2.gamma"), n128)),
+            }
+            Hd, Hp = cfg.ffn_hidden, self.hid_pad
+            if cfg.ffn == "swiglu":
+                w12, b12 = g(p + "mlp.w12.weight"), g(p + "mlp.w12.bias")
+                a_w, b_w = torch.zeros(Hp, C), torch.zeros(Hp, C)
+                a_b, b_b = torch.zeros(Hp), torch.zeros(Hp)
+                a_w[:Hd], b_w[:Hd], a_b[:Hd], b_b[:Hd] = w12[:Hd], w12[Hd:], b12[:Hd], b12[Hd:]
+                # interleave in blocks of 8 so one lane's 16 accumulators are 8 gates + their 8 values (EpiSwiGLU)
+                inter_w = torch.stack([a_w.reshape(-1, 8, C), b_w.reshape(-1, 8, C)], dim=1).reshape(2 * Hp, C)
+                inter_b = torch.stack([a_b.reshape(-1, 8), b_b.reshape(-1, 8)], dim=1).reshape(2 * Hp)
+                blk["ffn1_w"] = up(_bf16_padded(inter_w, 2 * Hp, C))
+                blk["ffn1_b"] = up(inter_b)
+                blk["ffn2_w"] = up(_bf16_padded(g(p + "mlp.w3.weight"), n128, Hp))
+                blk["ffn2_b"] = up(_f32_padded(g(p + "mlp.w3.bias"), n128))
+            else:
+                blk["ffn1_w"] = up(_bf16_padded(g(p + "mlp.fc1.weight"), Hp, C))
+                blk["ffn1_b"] = up(_f32_padded(g(p + "mlp.fc1.bias"), Hp))
+                blk["ffn2_w"] = up(_bf16_padded(g(p + "mlp.fc2.weight"), n128, Hp))
+                blk["ffn2_b"] = up(_f32_padded(g(p + "mlp.fc2.bias"), n128))
+            blocks.append(blk)
+        self.w, self.blocks = w, blocks
+
+    def weight_bytes(self) -> int:
+        n = sum(t.numel() * t.element_size() for t in self.w.values())
+        return n + sum(t.numel() * t.element_size() for b in self.blocks for t in b.values())
+
+    # ---- per-shape state ------------------------------------------------------------------------------------------
+    def geometry(self, H: int, W: int):
+        """raw slice size -> (hp, wp, tokens, padded tokens, padded keys)"""
+        return self._geometry(math.ceil(H / 16), math.ceil(W / 16))  # (ceil16(H)*14/16)/14
+
+    def _geometry(self, hp: int, wp: int):
+        nt = hp * wp + 1 + self.cfg.n_reg
+        return hp, wp, nt, round_up(nt, 8), round_up(nt, 64)
+
+    def _pos_for(self, hp: int, wp: int):
+        key = (hp, wp)
+        if key not in self._pos:
+            pos = interpolate_pos_embed(self.cfg, self._pos_src, hp, wp)
+            cls_pos0 = self._cls + pos[0]
+            self._pos[key] = (pos.to(self.device), cls_pos0.to(self.device))
+        return self._pos[key]
+
+    def _workspace(self, b: int, hp: int, wp: int):
+        key = (b, hp, wp)
+        if key in self._ws:
+            return self._ws[key]
+        cfg, dev = self.cfg, self.device
+        _, _, nt, ntp, kp = self._geometry(hp, wp)
+        C = cfg.dim
+        rows = alloc_rows(b * ntp)
+        z = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        ws = {
+            "ape": z(alloc_rows(b * hp * wp), 640),
+            "x": z(rows, C, dt=torch.float32),
+            "xn": z(rows, C),
+            "qk": z(rows, 2 * C),
+            "vt": z(b, cfg.heads, 64, kp),
+            "ao": z(rows, C),
+            "hid": z(rows, self.hid_pad),
+        }
+        self._ws = {key: ws}  # keep one shape resident
+        return ws
+
+    # ---- forward ----------------------------------------------------------------------------------------------------
+    def features(self, slices: torch.Tensor, feats_f16=None, d_total: int = 0, d0: int = 0, feats_cl=None) -> None:
+        """slices: device uint8/float32 [b,H,W] (raw tomogram slices).  Writes
+        feats_f16 fp16 [C, d_total, hp, wp] at depth d0..d0+b-1 and/or feats_cl bf16 [b, hp, wp, C]."""
+        b, H, W = slices.shape
+        hp, wp = math.ceil(H / 16), math.ceil(W / 16)
+        ws = self._workspace(b, hp, wp)
+        ape = ws["ape"].view(-1)[: ws["ape"].shape[0] * 256].view(-1, 256)  # K = 196 -> 256 view of the patch matrix
+        ops.preprocess_patches(slices, ape)
+        self._encode(b, hp, wp, ape, self.w["pe_w"], feats_f16, d_total, d0, feats_cl, None)
+
+    @torch.inference_mode()
+    def forward_features(self, x: torch.Tensor) -> dict:
+        """The reference's encoder protocol (run/dino_features.py:58): x fp32 [b,3,H',W'] already resized,
+        H', W' multiples of 14 -> {"x_norm_patchtokens": fp32 [b, (H'/14)*(W'/14), C]} on the device."""
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 14 or x.shape[3] % 14:
+            raise ValueError(f"forward_features expects [b,3,H,W] with H,W multiples of 14, got {tuple(x.shape)}")
+        x = x.to(self.device, torch.float32).contiguous()
+        b, hp, wp = x.shape[0], x.shape[2] // 14, x.shape[3] // 14
+        ws = self._workspace(b, hp, wp)
+        ops.im2col_patches(x, ws["ape"])
+        tokens = torch.empty(b, hp * wp, self.cfg.dim, dtype=torch.float32, device=self.device)
+        self._encode(b, hp, wp, ws["ape"], self.w["pe3_w"], None, 0, 0, None, tokens)
+        return {"x_norm_patchtokens": tokens}
+
+    def _encode(self, b, hp, wp, ape, pe_w, feats_f16, d_total, d0, feats_cl, tokens_f32) -> None:
+        cfg = self.cfg
+        _, _, nt, ntp, kp = self._geometry(hp, wp)
+        C, npatch, tok0 = cfg.dim, hp * wp, 1 + cfg.n_reg
+        ws, w = self._workspace(b, hp, wp), self.w
+        pos, cls_pos0 = self._pos_for(hp, wp)
+        M = b * ntp
+
+        ops.init_tokens(ws["x"], cls_pos0, w["reg"], n_reg=cfg.n_reg, slices=b, ntok=nt, ntp=ntp, Cdim=C)
+        ops.gemm(EPI_PATCH, ape, pe_w, ws["x"], w["pe_b"], m=b * npatch, n=C, pos=pos, npatch=npatch, ntp=ntp, tok0=tok0)
+        for blk in self.blocks:
+            ops.layernorm(ws["x"], blk["ln1_w"], blk["ln1_b"], ws["xn"], M, C, cfg.ln_eps)
+            ops.gemm(EPI_BF16, ws["xn"], blk["qk_w"], ws["qk"], blk["qk_b"], m=M, n=2 * C)
+            ops.gemm(EPI_VT, ws["xn"], blk["v_w"], ws["vt"], blk["v_b"], m=M, n=C, heads=cfg.heads, ntp=ntp, kp=kp, ldc=0)
+            ops.attention(ws["qk"], ws["vt"], ws["ao"], slices=b, heads=cfg.heads, ntok=nt, ntp=ntp, kp=kp)
+            ops.gemm(EPI_RESID, ws["ao"], blk["proj_w"], ws["x"], blk["proj_b"], m=M, n=C, gamma=blk["ls1"])
+            ops.layernorm(ws["x"], blk["ln2_w"], blk["ln2_b"], ws["xn"], M, C, cfg.ln_eps)
+            if cfg.ffn == "swiglu":
+                ops.gemm(EPI_SWIGLU, ws["xn"], blk["ffn1_w"], ws["hid"], blk["ffn1_b"], m=M, n=2 * self.hid_pad)
+            else:
+                ops.gemm(EPI_BF16_GELU, ws["xn"], blk["ffn1_w"], ws["hid"], blk["ffn1_b"], m=M, n=self.hid_pad)
+            ops.gemm(EPI_RESID, ws["hid"], blk["ffn2_w"], ws["x"], blk["ffn2_b"], m=M, n=C, gamma=blk["ls2"])
+        ops.final_norm_features(ws["x"], w["norm_w"], w["norm_b"], cfg.ln_eps, slices=b, ntp=ntp, tok0=tok0, hp=hp, wp=wp,
+                                Cdim=C, feats_f16=feats_f16, d_total=d_total, d0=d0, feats_cl=feats_cl, tokens_f32=tokens_f32)
+
+    def flops(self, b: int, H: int, W: int) -> float:
+        """Algorithmic FLOPs (2*MACs of linears + attention matmuls + patch embed, SURVEY s.8d) for b slices."""
+        cfg = self.cfg
+        hp, wp, nt, _, _ = self.geometry(H, W)
+        C, Hd = cfg.dim, cfg.ffn_hidden
+        lin = 2 * (3 * C * C + C * C + (3 if cfg.ffn == "swiglu" else 2) * C * Hd)
+        per_tok_layer = lin + 4 * nt * C
+        return b * (cfg.depth * nt * per_tok_layer + 2 * hp * wp * 588 * C)

@@ -1,0 +1,151 @@
+/* cryovit_hip.h -- C ABI of libcryovit_hip.so (gfx950 / MI355X).
+ *
+ * The reference (VivianDLi/CryoVIT) is pure Python and has NO FFI boundary of its own: its plug-in
+ * surface is Hydra `_target_` instantiation plus two duck-typed Python protocols.  This
+ * header is therefore the boundary a maintainer would bind with ctypes to replace the third-party
+ * arithmetic the reference delegates to torch / xformers / the dinov2 hub model:
+ *
+ *   cvx_vit_forward   replaces  model.forward_features(vec)["x_norm_patchtokens"] + reshape/permute/half
+ *                               src/cryovit/run/dino_features.py:53-61  (and the CPU bicubic resize of
+ *                               src/cryovit/datasets/vit_dataset.py:117-123, which it fuses)
+ *   cvx_head_forward  replaces  CryoVIT.forward_volume + sigmoid          src/cryovit/models/cryovit.py:36-49
+ *                               and the masked Dice reductions            src/cryovit/models/base_model.py:99-110,
+ *                                                                         src/cryovit/models/metrics.py:30-43
+ *
+ * Conventions: every function returns 0 on success and a negative code on failure
+ * (cvx_last_error() gives the message, thread-local); all pointers named *_dev / in descriptors are DEVICE
+ * pointers owned by the caller; nothing allocates, frees or synchronises inside a call (graph-capturable);
+ * every launch goes to the caller's hipStream_t.  One handle per stream / GPU; handles are not thread-safe.
+ * The op-level entry points (cvx_gemm_bf16 ... cvx_dice_sums) are the kernels the two high-level calls are
+ * built from; they are exported so the parity tests can check each kernel against the CPU oracle.
+ */
+#ifndef CRYOVIT_HIP_H
+#define CRYOVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t; /* same as <hip/hip_runtime_api.h> */
+
+#define CVX_OK 0
+#define CVX_ERR_ARG (-1)
+#define CVX_ERR_HIP (-2)
+
+const char* cvx_last_error(void);
+int cvx_version(void);
+/* name of the device the library would launch on ("gfx950...") or "" when no HIP device is visible */
+int cvx_device_arch(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dense GEMM  C[M,N] = A[M,K] * W[N,K]^T, bf16 operands (K contiguous, leading dims in elements),
+ * fp32 accumulation on v_mfma_f32_16x16x32_bf16, fused epilogue.  A must be allocated (not necessarily
+ * valid) up to a multiple of 256 rows; W / bias / gamma are packed to n_pad (multiple of 16; 128 for
+ * SWIGLU / VT) rows and k_pad (multiple of 64) columns.  Replaces torch.nn.Linear / Conv2d(14,14) /
+ * Conv3d(k=1) / ConvTranspose3d calls made by the hub ViT and by cryovit/models/cryovit.py:18-34,74-77.
+ * ------------------------------------------------------------------------------------------------- */
+enum cvx_epilogue {
+    CVX_EPI_BF16 = 0,      /* out bf16 [M][ldc]       = acc + bias                                   */
+    CVX_EPI_BF16_GELU = 1, /* out bf16 [M][ldc]       = gelu_erf(acc + bias)                         */
+    CVX_EPI_SWIGLU = 2,    /* out bf16 [M][ldc], N/2 cols = silu(a) * b   (W rows interleaved by 8)  */
+    CVX_EPI_RESID = 3,     /* out fp32 [M][ldc]      += gamma * (acc + bias)     (LayerScale+residual)*/
+    CVX_EPI_PATCH = 4,     /* out fp32 token stream: row slice*ntp+tok0+p = acc + bias + pos[1+p]     */
+    CVX_EPI_VT = 5,        /* out bf16 V^T [slice][head][64][kp] = acc + bias   (for cvx_attention)   */
+    CVX_EPI_CONVT = 6      /* out bf16 [D][2H][2W][cout] pixel-shuffle of N = 4*cout, optional GELU   */
+};
+
+typedef struct cvx_gemm_desc {
+    int epilogue;
+    const void* a; long lda;   /* bf16 [M_alloc][lda]  */
+    const void* w; long ldw;   /* bf16 [n_pad][ldw]    */
+    long m, n, n_pad, k_pad;   /* valid rows / cols; padded N, K */
+    void* out; long ldc;
+    const float* bias;         /* [n_pad] */
+    const float* gamma;        /* RESID: [n_pad] */
+    const float* pos; long ldpos; /* PATCH: fp32 [1+npatch][ldpos] */
+    int npatch, ntp, tok0;     /* PATCH: patches per slice, padded tokens per slice, first patch token */
+    int heads, kp;             /* VT: heads, padded key count (multiple of 64) */
+    int H, W, cout, act;       /* CONVT: input plane size, C_out, act (0 none / 1 GELU) */
+} cvx_gemm_desc;
+
+int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t stream);
+
+/* Dilated 3x3x3 "same" convolution, dilation (dil,1,1), channels-last bf16 volume in[D][H][W][C] ->
+ * out[D][H][W][cout] = act(conv + bias), as an implicit GEMM (K = tap*C + c).  w is bf16 [n_pad][k_pad] with
+ * k = ((kz*3+ky)*3+kx)*C + c.  zero_page: >= 16 zero bytes on the device (source of padded taps).
+ * Replaces nn.Conv3d(c1,c2,3,padding="same",dilation=(d,1,1)) -- cryovit/models/cryovit.py:70-73,30-33. */
+typedef struct cvx_conv3d_desc {
+    const void* in; const void* w; const float* bias; const void* zero_page; void* out;
+    int C, D, H, W, dil, cout, n_pad, k_pad, act;
+} cvx_conv3d_desc;
+int cvx_conv3d_bf16(const cvx_conv3d_desc* d, hipStream_t stream);
+
+/* LayerNorm over the last dim of an fp32 token stream -> bf16 (GEMM operand).  eps inside the sqrt.
+ * x fp32 [rows][ldx], out bf16 [rows][ldo].  Replaces nn.LayerNorm(C, eps=1e-6) in the hub ViT blocks. */
+int cvx_layernorm_bf16(const float* x, long ldx, const float* w, const float* b, void* out, long ldo, long rows,
+                       int C, float eps, hipStream_t stream);
+
+/* Multi-head attention, head_dim 64, no mask/dropout:  O = softmax(Q K^T) V  per (slice, head).
+ *   qk   bf16 [slices*ntp (+64 rows slack)][ldqk] : columns [0,C) = Q (pre-scaled by head_dim^-0.5),
+ *                                                  [C,2C) = K, head h at columns h*64..h*64+63
+ *   vt   bf16 [slices][heads][64][kp]  (kp = ntok rounded up to 64; columns >= ntok must be finite)
+ *   out  bf16 [slices*ntp][ldo], head h at columns h*64...
+ * ntok = valid tokens per slice (keys >= ntok are masked), ntp = padded tokens per slice (multiple of 8).
+ * Replaces xformers.memory_efficient_attention inside the hub model (run/dino_features.py:58). */
+int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
+                       int ntok, int ntp, int kp, hipStream_t stream);
+
+/* Pre-processing fused with im2col: raw slices [b][H][W] (u8 -> /255, or f32), edge-pad to x16, bicubic
+ * x14/16 (A = -0.75, align_corners = False, clamped taps), cut into 14x14 patches of ONE channel (the 3
+ * input channels are identical copies -- vit_dataset.py:117-118 -- so the patch-embed weight is summed over
+ * channels at pack time): out bf16 [b*hp*wp][k_pad], k = py*14+px, zero padded to k_pad.
+ * Replaces VITDataset._dino_transform (vit_dataset.py:90-123) + the unfold inside Conv2d(3,C,14,14). */
+int cvx_preprocess_patches(const void* slices, int is_u8, int b, int H, int W, void* out, int k_pad,
+                           hipStream_t stream);
+
+/* cls / register / padding rows of the token stream: x[s*ntp + 0] = cls + pos[0]; rows 1..n_reg = registers;
+ * rows ntok..ntp-1 = 0.  (patch rows are written by CVX_EPI_PATCH.) */
+int cvx_init_tokens(float* x, long ldx, const float* cls_pos0, const float* reg, int n_reg, int slices, int ntok,
+                    int ntp, int C, hipStream_t stream);
+
+/* Final LayerNorm + drop cls/registers + layout transform (run/dino_features.py:58-61):
+ *   feats_f16  (nullable) fp16 [C][d_total][hp][wp], slices written at depth d0..d0+slices-1
+ *   feats_cl   (nullable) bf16 [slices][hp][wp][C]   channels-last copy for the segmentation head
+ *   tokens_f32 (nullable) fp32 [slices][hp*wp][C]    "x_norm_patchtokens" of the encoder protocol */
+int cvx_final_norm_features(const float* x, long ldx, const float* w, const float* b, float eps, int slices,
+                            int ntp, int tok0, int hp, int wp, int C, void* feats_f16, long d_total, long d0,
+                            void* feats_cl, float* tokens_f32, hipStream_t stream);
+
+/* im2col of already-resized 3-channel images x fp32 [b][3][Hi][Wi] (Hi, Wi multiples of 14) for the
+ * encoder-protocol entry point forward_features(x) (run/dino_features.py:58): out bf16 [b*hp*wp][k_pad],
+ * k = c*196 + py*14 + px (the flattening of Conv2d(3,C,14,14).weight), zero padded to k_pad >= 588. */
+int cvx_im2col_patches(const float* x, int b, int Hi, int Wi, void* out, int k_pad, hipStream_t stream);
+
+/* fp16 [C][D][h][w] (the HDF5 `dino_features` layout) -> bf16 channels-last [D][h][w][C] */
+int cvx_features_to_channels_last(const void* feats_f16, void* out_cl, int C, long nvox, hipStream_t stream);
+
+/* GroupNorm over a channels-last bf16 volume x[nvox][C], G groups, biased variance, eps inside sqrt
+ * (nn.GroupNorm(G, C, eps=1e-3) -- cryovit.py:69).  Two launches: stats (sum, sumsq per group into
+ * stats[2*G] fp32, zeroed by the call) then apply -> bf16 out. */
+int cvx_groupnorm_bf16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
+                       int G, float eps, hipStream_t stream);
+
+/* Last layer of the head at full resolution, channels-last bf16 in[D][H][W][8]:
+ *   conv3x3x3(8->1, w fp32 [27][8] tap-major) + bias, clip(+-5) -> logits fp32 (nullable), sigmoid -> probs fp32
+ *   (nullable), and masked Dice partial sums (labels int8 nullable; dice must be zeroed by the caller):
+ *   dice[0] += sum(y*p_hat), dice[1] += sum(y), dice[2] += sum(p_hat) over labels > -1, p_hat = (p >= 0.5).
+ * Replaces output_layer.2 + clip + sigmoid (cryovit.py:33,39,49) and the reductions of
+ * base_model.py:99-110 / metrics.py:36-41.  (output_layer.0 + GELU runs through cvx_conv3d_bf16.) */
+int cvx_conv3_out_fused(const void* in, const float* w, float bias, float* logits, float* probs, const int8_t* labels,
+                        float* dice, int D, int H, int W, hipStream_t stream);
+
+/* Masked Dice partial sums over existing predictions (same definition as above, threshold thr). */
+int cvx_dice_sums(const float* probs, const int8_t* labels, float* dice, long n, float thr, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRYOVIT_HIP_H */

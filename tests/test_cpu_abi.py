@@ -1,0 +1,65 @@
+"""CPU suite, part 2: the C-ABI library builds for gfx950, loads without a GPU and exports every declared symbol;
+the product path refuses to run without a device (no CPU fallback)."""
+
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from cryovit_amd import _lib
+    from cryovit_amd.build import build_library
+
+    build_library()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    from cryovit_amd import _lib
+
+    header = (ROOT / "include" / "cryovit_hip.h").read_text()
+    declared = set(re.findall(r"\b(cvx_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_version_and_error_string(lib):
+    assert lib.cvx_version() >= 1
+    assert isinstance(lib.cvx_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu(lib):
+    # descriptor-less / malformed calls must fail with a message before touching the device
+    from cryovit_amd._lib import CvxError, check
+
+    with pytest.raises(CvxError, match="null descriptor"):
+        check(lib.cvx_gemm_bf16(None, None), "cvx_gemm_bf16")
+    with pytest.raises(CvxError, match="ntp%8"):
+        check(lib.cvx_attention_bf16(None, 8, None, None, 8, 1, 1, 10, 10, 64, None), "cvx_attention_bf16")
+
+
+def test_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cryovit_amd._lib import CvxError
+    from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine
+
+    with pytest.raises(CvxError):
+        VitEngine(VIT_CONFIGS["dinov2_vits14_reg"], {}, "cuda:0")
+    from cryovit_amd.engine import ops
+
+    with pytest.raises(CvxError):
+        ops.layernorm(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), torch.zeros(4, 8, dtype=torch.bfloat16), 4, 8, 1e-6)
+
+
+def test_product_never_imports_oracle():
+    for f in (ROOT / "cryovit_amd").rglob("*.py"):
+        src = f.read_text()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"

@@ -1,0 +1,323 @@
+"""Kernel-level parity: every HIP op (through the C ABI) against a torch-CPU fp32 computation of the same op on the
+same bf16-rounded operands.  Tolerances are stated per test; bf16 has 8 significand bits (rel. 2^-9 per rounding)."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def padded_bf16(t, rows, cols, dev):
+    out = torch.zeros(rows, cols, dtype=torch.bfloat16)
+    out[: t.shape[0], : t.shape[1]] = bf(t)
+    return out.to(dev)
+
+
+def padded_f32(v, n, dev):
+    out = torch.zeros(n)
+    out[: v.numel()] = v
+    return out.to(dev)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (1000, 192, 128), (257, 40, 64), (130, 16, 320), (4096, 1536, 1536)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_bf16(gpu, M, N, K, gelu):
+    from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _npad
+
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K**-0.5), rnd(N, seed=3)
+    n_pad, k_pad = _npad(N), ops.round_up(K, 64)
+    A = padded_bf16(a, ops.alloc_rows(M), k_pad, gpu)
+    Wd = padded_bf16(w, n_pad, k_pad, gpu)
+    out = torch.full((ops.alloc_rows(M), N), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_BF16_GELU if gelu else EPI_BF16, A, Wd, out, padded_f32(b, n_pad, gpu), m=M, n=N)
+    ref = bf(a).float() @ bf(w).float().T + b
+    ref = F.gelu(ref) if gelu else ref
+    got = out[:M].float().cpu()
+    # bf16 output rounding (2^-9 relative) + fp32 accumulation order
+    assert torch.allclose(got, ref, atol=2e-2, rtol=1e-2), float((got - ref).abs().max())
+    assert torch.all(out[M:].float() == 7.0), "rows beyond M were written"
+
+
+def test_gemm_swiglu(gpu):
+    from cryovit_amd._lib import EPI_SWIGLU
+    from cryovit_amd.engine import ops
+
+    M, K, Hd = 500, 128, 344  # hidden not a multiple of 64 -> padded to 384
+    Hp = ops.round_up(Hd, 64)
+    a, w12, b12 = rnd(M, K, seed=4), rnd(2 * Hd, K, seed=5, scale=K**-0.5), rnd(2 * Hd, seed=6)
+    aw, bw, ab, bb = torch.zeros(Hp, K), torch.zeros(Hp, K), torch.zeros(Hp), torch.zeros(Hp)
+    aw[:Hd], bw[:Hd], ab[:Hd], bb[:Hd] = w12[:Hd], w12[Hd:], b12[:Hd], b12[Hd:]
+    iw = torch.stack([aw.reshape(-1, 8, K), bw.reshape(-1, 8, K)], 1).reshape(2 * Hp, K)
+    ib = torch.stack([ab.reshape(-1, 8), bb.reshape(-1, 8)], 1).reshape(2 * Hp)
+    A = padded_bf16(a, ops.alloc_rows(M), K, gpu)
+    out = torch.zeros(ops.alloc_rows(M), Hp, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_SWIGLU, A, bf(iw).to(gpu), out, ib.to(gpu), m=M, n=2 * Hp)
+    h = bf(a).float() @ bf(w12).float().T + b12
+    ref = F.silu(h[:, :Hd]) * h[:, Hd:]
+    got = out[:M].float().cpu()
+    assert torch.allclose(got[:, :Hd], ref, atol=2e-2, rtol=1e-2), float((got[:, :Hd] - ref).abs().max())
+    assert torch.all(got[:, Hd:] == 0)
+
+
+def test_gemm_resid(gpu):
+    from cryovit_amd._lib import EPI_RESID
+    from cryovit_amd.engine import ops
+
+    M, N, K = 700, 384, 256
+    a, w, b, g, x0 = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=K**-0.5), rnd(N, seed=9), rnd(N, seed=10), rnd(M, N, seed=11)
+    A = padded_bf16(a, ops.alloc_rows(M), K, gpu)
+    x = torch.zeros(ops.alloc_rows(M), N, device=gpu)
+    x[:M] = x0.to(gpu)
+    ops.gemm(EPI_RESID, A, padded_bf16(w, N, K, gpu), x, b.to(gpu), m=M, n=N, gamma=g.to(gpu))
+    ref = x0 + g * (bf(a).float() @ bf(w).float().T + b)
+    assert torch.allclose(x[:M].cpu(), ref, atol=1e-4, rtol=1e-4), float((x[:M].cpu() - ref).abs().max())  # fp32 out
+    assert torch.all(x[M:] == 0)
+
+
+def test_gemm_patch_and_tokens(gpu):
+    from cryovit_amd._lib import EPI_PATCH
+    from cryovit_amd.engine import ops
+
+    b, npatch, C, K, n_reg = 3, 24, 128, 196, 4
+    nt = npatch + 1 + n_reg
+    ntp = ops.round_up(nt, 8)
+    a, w, bias = rnd(b * npatch, K, seed=12), rnd(C, K, seed=13, scale=K**-0.5), rnd(C, seed=14)
+    pos, cls, reg = rnd(1 + npatch, C, seed=15), rnd(C, seed=16), rnd(n_reg, C, seed=17)
+    A = padded_bf16(a, ops.alloc_rows(b * npatch), 256, gpu)
+    x = torch.full((ops.alloc_rows(b * ntp), C), 5.0, device=gpu)
+    ops.init_tokens(x, (cls + pos[0]).to(gpu), reg.to(gpu), n_reg=n_reg, slices=b, ntok=nt, ntp=ntp, Cdim=C)
+    ops.gemm(EPI_PATCH, A, padded_bf16(w, C, 256, gpu), x, bias.to(gpu), m=b * npatch, n=C, pos=pos.to(gpu), npatch=npatch,
+             ntp=ntp, tok0=1 + n_reg)
+    pe = (bf(a).float() @ bf(w).float().T + bias).reshape(b, npatch, C) + pos[1:]
+    got = x[: b * ntp].cpu().reshape(b, ntp, C)
+    assert torch.allclose(got[:, 1 + n_reg : nt], pe, atol=1e-4, rtol=1e-4)
+    assert torch.equal(got[:, 0], (cls + pos[0]).expand(b, C))
+    assert torch.equal(got[:, 1 : 1 + n_reg], reg.expand(b, n_reg, C))
+    assert torch.all(got[:, nt:] == 0)
+
+
+def test_gemm_vt(gpu):
+    from cryovit_amd._lib import EPI_VT
+    from cryovit_amd.engine import ops
+
+    b, heads, nt, K = 3, 2, 29, 128
+    ntp, kp, C = ops.round_up(nt, 8), 64, heads * 64
+    M = b * ntp
+    a, w, bias = rnd(M, K, seed=18), rnd(C, K, seed=19, scale=K**-0.5), rnd(C, seed=20)
+    A = padded_bf16(a, ops.alloc_rows(M), K, gpu)
+    vt = torch.zeros(b, heads, 64, kp, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_VT, A, padded_bf16(w, C, K, gpu), vt, bias.to(gpu), m=M, n=C, heads=heads, ntp=ntp, kp=kp, ldc=0)
+    v = (bf(a).float() @ bf(w).float().T + bias).reshape(b, ntp, heads, 64).permute(0, 2, 3, 1)  # [b,h,d,t]
+    got = vt.float().cpu()
+    assert torch.allclose(got[..., :ntp], v, atol=2e-2, rtol=1e-2), float((got[..., :ntp] - v).abs().max())
+    assert torch.all(got[..., ntp:] == 0)
+
+
+@pytest.mark.parametrize("C", [128, 384, 1536])
+def test_layernorm(gpu, C):
+    from cryovit_amd.engine import ops
+
+    rows = 1030
+    x = rnd(rows, C, seed=21) * 3 + 0.5
+    w, b = rnd(C, seed=22) + 1, rnd(C, seed=23)
+    out = torch.zeros(rows, C, dtype=torch.bfloat16, device=gpu)
+    ops.layernorm(x.to(gpu), w.to(gpu), b.to(gpu), out, rows, C, 1e-6)
+    ref = F.layer_norm(x, (C,), w, b, 1e-6)
+    assert torch.allclose(out.float().cpu(), ref, atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3)])
+def test_attention(gpu, nt, slices, heads):
+    from cryovit_amd.engine import ops
+
+    C = heads * 64
+    ntp, kp = ops.round_up(nt, 8), ops.round_up(nt, 64)
+    M = slices * ntp
+    q, k, v = rnd(slices, nt, heads, 64, seed=24), rnd(slices, nt, heads, 64, seed=25), rnd(slices, nt, heads, 64, seed=26)
+    q = q * 1.5  # spread the logits so the online-softmax rescale path is exercised
+    qk = torch.randn(ops.alloc_rows(M), 2 * C, generator=torch.Generator().manual_seed(27)).to(torch.bfloat16)  # junk pad
+    qkv = qk[:M].reshape(slices, ntp, 2 * C)
+    qkv[:, :nt, :C] = bf(q * 0.125).reshape(slices, nt, C)
+    qkv[:, :nt, C:] = bf(k).reshape(slices, nt, C)
+    vt = torch.zeros(slices, heads, 64, kp, dtype=torch.bfloat16)
+    vt[..., :nt] = bf(v).permute(0, 2, 3, 1)
+    vt[..., nt:ntp] = 3.0  # finite garbage in the pad tokens must be masked out
+    out = torch.zeros(ops.alloc_rows(M), C, dtype=torch.bfloat16, device=gpu)
+    ops.attention(qk.to(gpu), vt.to(gpu), out, slices=slices, heads=heads, ntok=nt, ntp=ntp, kp=kp)
+    qf, kf, vf = bf(q * 0.125).float(), bf(k).float(), bf(v).float()
+    att = torch.softmax(torch.einsum("snhd,smhd->shnm", qf, kf), dim=-1)
+    ref = torch.einsum("shnm,smhd->snhd", att, vf).reshape(slices, nt, C)
+    got = out[:M].float().cpu().reshape(slices, ntp, C)
+    # P is rounded to bf16 before PV (rel 2^-9) and the output is bf16
+    assert torch.allclose(got[:, :nt], ref, atol=2e-2, rtol=2e-2), float((got[:, :nt] - ref).abs().max())
+    assert torch.all(got[:, nt:] == 0), "padding rows must not be written"
+
+
+def test_attention_forced_rescale(gpu):
+    """One key row spiked against one query so the running max jumps in a late tile (rare-branch test)."""
+    from cryovit_amd.engine import ops
+
+    nt, slices, heads, C = 200, 1, 1, 64
+    ntp, kp = ops.round_up(nt, 8), ops.round_up(nt, 64)
+    q, k, v = rnd(1, nt, 1, 64, seed=28), rnd(1, nt, 1, 64, seed=29), rnd(1, nt, 1, 64, seed=30)
+    k[0, 150, 0] = q[0, 7, 0] * 4.0
+    qk = torch.zeros(ops.alloc_rows(ntp), 2 * C, dtype=torch.bfloat16)
+    qk[:nt, :C], qk[:nt, C:] = bf(q * 0.125).reshape(nt, C), bf(k).reshape(nt, C)
+    vt = torch.zeros(1, 1, 64, kp, dtype=torch.bfloat16)
+    vt[0, 0, :, :nt] = bf(v).reshape(nt, 64).T
+    out = torch.zeros(ops.alloc_rows(ntp), C, dtype=torch.bfloat16, device=gpu)
+    ops.attention(qk.to(gpu), vt.to(gpu), out, slices=1, heads=1, ntok=nt, ntp=ntp, kp=kp)
+    qf, kf, vf = bf(q * 0.125).float().reshape(nt, 64), bf(k).float().reshape(nt, 64), bf(v).float().reshape(nt, 64)
+    ref = torch.softmax(qf @ kf.T, -1) @ vf
+    got = out[:nt].float().cpu()
+    assert torch.allclose(got, ref, atol=2e-2, rtol=2e-2), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["u8", "f32"])
+def test_preprocess_patches(gpu, gold, dtype):
+    from cryovit_amd.engine import ops
+
+    g = gold("preprocess.npz")
+    vol, ref = (g["vol_u8"], g["out_u8"]) if dtype == "u8" else (g["vol_f32"], g["out_f32"])
+    b, H, W = vol.shape
+    hp, wp = math.ceil(H / 16), math.ceil(W / 16)
+    out = torch.zeros(ops.alloc_rows(b * hp * wp), 256, dtype=torch.bfloat16, device=gpu)
+    ops.preprocess_patches(torch.from_numpy(vol).to(gpu), out)
+    got = out[: b * hp * wp].float().cpu().reshape(b, hp, wp, 256)
+    assert torch.all(got[..., 196:] == 0)
+    img = got[..., :196].reshape(b, hp, wp, 14, 14).permute(0, 1, 3, 2, 4).reshape(b, hp * 14, wp * 14)
+    reft = torch.from_numpy(ref)
+    # fixture = the reference's own _dino_transform output; bf16 storage of values in [-0.1, 1.1]
+    assert torch.allclose(img, bf(reft).float(), atol=4e-3, rtol=0), float((img - reft).abs().max())
+
+
+def test_final_norm_and_k9_layout(gpu):
+    from cryovit_amd.engine import ops
+
+    b, hp, wp, C, n_reg = 3, 4, 6, 128, 4
+    npatch, nt = hp * wp, hp * wp + 5
+    ntp = ops.round_up(nt, 8)
+    x = rnd(b, ntp, C, seed=31) * 2 + 0.3
+    w, bb = rnd(C, seed=32) + 1, rnd(C, seed=33)
+    d_total, d0 = 5, 1
+    f16 = torch.full((C, d_total, hp, wp), -9.0, dtype=torch.float16, device=gpu)
+    cl = torch.zeros(b, hp, wp, C, dtype=torch.bfloat16, device=gpu)
+    ops.final_norm_features(x.reshape(-1, C).to(gpu), w.to(gpu), bb.to(gpu), 1e-6, slices=b, ntp=ntp, tok0=1 + n_reg, hp=hp, wp=wp,
+                            Cdim=C, feats_f16=f16, d_total=d_total, d0=d0, feats_cl=cl)
+    ref = F.layer_norm(x[:, 1 + n_reg : nt], (C,), w, bb, 1e-6)  # [b, npatch, C]
+    ref_k9 = ref.reshape(b, hp, wp, C).permute(3, 0, 1, 2)  # run/dino_features.py:59-60
+    got = f16.float().cpu()
+    assert torch.allclose(got[:, d0 : d0 + b], ref_k9, atol=3e-3, rtol=2e-3)  # fp16 store
+    assert torch.all(got[:, :d0] == -9.0) and torch.all(got[:, d0 + b :] == -9.0)
+    assert torch.allclose(cl.float().cpu().reshape(b, npatch, C), ref, atol=2e-2, rtol=1e-2)
+
+
+def test_features_to_channels_last(gpu):
+    from cryovit_amd.engine import ops
+
+    C, D, h, w = 136, 3, 5, 7
+    f = rnd(C, D, h, w, seed=34).half()
+    out = torch.zeros(D * h * w, C, dtype=torch.bfloat16, device=gpu)
+    ops.features_to_channels_last(f.to(gpu), out)
+    ref = bf(f.float().reshape(C, -1).T)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("C,G", [(128, 16), (32, 8), (8, 8), (1024, 128)])
+def test_groupnorm(gpu, C, G):
+    from cryovit_amd.engine import ops
+
+    D, H, W = 5, 6, 7
+    x = bf(rnd(D, H, W, C, seed=35) * 1.5 + 0.4)
+    w, b = rnd(C, seed=36) + 1, rnd(C, seed=37)
+    out = torch.zeros_like(x, device=gpu)
+    stats = torch.zeros(2 * G, device=gpu)
+    ops.groupnorm(x.to(gpu), w.to(gpu), b.to(gpu), out, stats, nvox=D * H * W, Cdim=C, G=G, eps=1e-3)
+    ref = F.group_norm(x.float().permute(3, 0, 1, 2).unsqueeze(0), G, w, b, 1e-3)[0].permute(1, 2, 3, 0)
+    assert torch.allclose(out.float().cpu(), ref, atol=3e-2, rtol=1e-2), float((out.float().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("Cin,Cout,dil,D,H,W", [(128, 24, 32, 8, 4, 4), (32, 16, 2, 6, 8, 8), (8, 8, 1, 5, 9, 11), (192, 192, 3, 7, 5, 6),
+                                               (64, 64, 12, 16, 8, 8)])
+def test_conv3d(gpu, Cin, Cout, dil, D, H, W):
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _conv3_weight, _npad, _pad1
+
+    x = bf(rnd(D, H, W, Cin, seed=38))
+    w, b = rnd(Cout, Cin, 3, 3, 3, seed=39, scale=(27 * Cin) ** -0.5), rnd(Cout, seed=40)
+    nv = D * H * W
+    out = torch.full((nv + 8, Cout), 7.0, dtype=torch.bfloat16, device=gpu)
+    zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
+    ops.conv3d(x.to(gpu), _conv3_weight(w).to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=Cin, D=D, H=H, W=W, dil=dil,
+               cout=Cout, act=1)
+    ref = F.gelu(F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), bf(w).float(), b, padding="same", dilation=(dil, 1, 1)))
+    ref = ref[0].permute(1, 2, 3, 0).reshape(nv, Cout)
+    got = out[:nv].float().cpu()
+    assert torch.allclose(got, ref, atol=2e-2, rtol=1e-2), float((got - ref).abs().max())
+    assert torch.all(out[nv:].float() == 7.0)
+
+
+@pytest.mark.parametrize("c2,c3", [(24, 16), (192, 128), (16, 8)])
+def test_conv_transpose(gpu, c2, c3):
+    from cryovit_amd._lib import EPI_CONVT
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _npad, _pad1, _pad2
+
+    D, H, W = 3, 5, 6
+    nv = D * H * W
+    x = bf(rnd(nv, c2, seed=41))
+    wt, b = rnd(c2, c3, 1, 2, 2, seed=42, scale=c2**-0.5), rnd(c3, seed=43)
+    A = torch.zeros(ops.alloc_rows(nv) * c2 + 4096, dtype=torch.bfloat16)
+    A[: nv * c2] = x.reshape(-1)
+    A = A.to(gpu)
+    a2 = torch.as_strided(A, (ops.alloc_rows(nv), c2), (c2, 1))
+    wg = wt[:, :, 0].permute(2, 3, 1, 0).reshape(4 * c3, c2)
+    out = torch.zeros(D, 2 * H, 2 * W, c3, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_CONVT, a2, _pad2(wg, _npad(4 * c3), ops.round_up(c2, 64)).to(gpu), out, _pad1(b.repeat(4), _npad(4 * c3)).to(gpu),
+             m=nv, n=4 * c3, H=H, W=W, cout=c3, act=1, ldc=c3)
+    xin = x.float().reshape(D, H, W, c2).permute(3, 0, 1, 2).unsqueeze(0)
+    ref = F.gelu(F.conv_transpose3d(xin, bf(wt).float(), b, stride=(1, 2, 2)))[0].permute(1, 2, 3, 0)
+    assert torch.allclose(out.float().cpu(), ref, atol=2e-2, rtol=1e-2), float((out.float().cpu() - ref).abs().max())
+
+
+def test_conv3_out_fused_and_dice(gpu, gold):
+    from cryovit_amd.engine import ops
+
+    D, H, W = 6, 16, 70
+    x = bf(rnd(D, H, W, 8, seed=44))
+    w, b = rnd(1, 8, 3, 3, 3, seed=45, scale=0.3), 0.1
+    labels = torch.from_numpy(np.random.default_rng(46).integers(-1, 2, size=(D, H, W)).astype(np.int8))
+    logits = torch.zeros(D, H, W, device=gpu)
+    probs = torch.zeros(D, H, W, device=gpu)
+    dice = torch.zeros(3, device=gpu)
+    ops.conv3_out_fused(x.to(gpu), w[0].permute(1, 2, 3, 0).reshape(27, 8).contiguous().to(gpu), b, logits, probs, labels.to(gpu),
+                        dice, D=D, H=H, W=W)
+    ref = F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), w, torch.tensor([b]), padding="same")[0, 0].clip(-5, 5)
+    assert torch.allclose(logits.cpu(), ref, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(probs.cpu(), torch.sigmoid(ref), atol=1e-5)
+    # Dice sums must be exact integers given the GPU's own probabilities
+    p = probs.cpu()
+    mask = labels > -1
+    ph = (p >= 0.5).float()
+    exp = torch.tensor([float((labels.float() * ph)[mask].sum()), float(labels.float()[mask].sum()), float(ph[mask].sum())])
+    assert torch.equal(dice.cpu(), exp)
+    # stand-alone reduction against the reference-pinned fixture
+    g = gold("dice.npz")
+    d2 = torch.zeros(3, device=gpu)
+    ops.dice_sums(torch.from_numpy(g["preds"]).to(gpu), torch.from_numpy(g["labels"]).to(gpu), d2, 0.5)
+    i, sy, sp = d2.cpu().tolist()
+    assert abs(2 * i / (sy + sp + 1e-3) - float(g["dice"])) < 1e-6
