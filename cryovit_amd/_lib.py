@@ -72,6 +72,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so (SONAME libamdhip64.so.7).  It must be in the process BEFORE our library is
+    # dlopen()ed so that both bind to ONE HIP runtime; the other order gives two runtimes and "no ROCm-capable device".
+    import torch  # noqa: F401
+
     if not LIB_PATH.exists():
         raise CvxError(
             f"{LIB_PATH} not found: build it with `python -m cryovit_amd.build` (hipcc, gfx950). "

@@ -34,8 +34,12 @@ def _p(t) -> int | None:
 
 def _dev_check(*ts) -> None:
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise _lib.CvxError("cryovit_amd ops need device (HIP) tensors; there is no CPU path")
+        if not t.is_contiguous():  # the kernels index raw pointers: a strided view would be read as garbage
+            raise _lib.CvxError(f"non-contiguous tensor {tuple(t.shape)} strides {t.stride()} passed to a HIP op")
 
 
 def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, *, m: int, n: int,

@@ -60,15 +60,46 @@ VIT_CONFIGS = {
 
 
 def _bf16_padded(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
-    out = torch.zeros(n_pad, k_pad, dtype=torch.bfloat16)
+    out = torch.zeros(n_pad, k_pad, dtype=torch.bfloat16, device=w.device)
     out[: w.shape[0], : w.shape[1]] = w.to(torch.bfloat16)
     return out
 
 
 def _f32_padded(v: torch.Tensor, n_pad: int) -> torch.Tensor:
-    out = torch.zeros(n_pad, dtype=torch.float32)
+    out = torch.zeros(n_pad, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v.float().reshape(-1)
     return out
+
+
+def random_state_dict(cfg: "VitConfig", seed: int, device="cpu", std: float = 0.02) -> dict:
+    """Synthetic weights in the upstream key layout, generated on `device` (no checkpoint is
+    reachable offline).  N(0, std) linears, LayerNorm / LayerScale ~ 1 + N(0, std)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    C = cfg.dim
+
+    def n(*shape, mean=0.0):
+        return torch.empty(*shape, device=device).normal_(mean, std, generator=g)
+
+    sd = {
+        "cls_token": n(1, 1, C), "pos_embed": n(1, 1 + cfg.pos_grid**2, C), "register_tokens": n(1, cfg.n_reg, C),
+        "mask_token": torch.zeros(1, C, device=device),
+        "patch_embed.proj.weight": n(C, 3, 14, 14), "patch_embed.proj.bias": n(C),
+        "norm.weight": n(C, mean=1.0), "norm.bias": n(C),
+    }
+    for i in range(cfg.depth):
+        p = f"blocks.{i}."
+        sd[p + "norm1.weight"], sd[p + "norm1.bias"] = n(C, mean=1.0), n(C)
+        sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"] = n(3 * C, C), n(3 * C)
+        sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"] = n(C, C), n(C)
+        sd[p + "ls1.gamma"], sd[p + "ls2.gamma"] = n(C, mean=1.0), n(C, mean=1.0)
+        sd[p + "norm2.weight"], sd[p + "norm2.bias"] = n(C, mean=1.0), n(C)
+        if cfg.ffn == "swiglu":
+            sd[p + "mlp.w12.weight"], sd[p + "mlp.w12.bias"] = n(2 * cfg.ffn_hidden, C), n(2 * cfg.ffn_hidden)
+            sd[p + "mlp.w3.weight"], sd[p + "mlp.w3.bias"] = n(C, cfg.ffn_hidden), n(C)
+        else:
+            sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"] = n(cfg.ffn_hidden, C), n(cfg.ffn_hidden)
+            sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"] = n(C, cfg.ffn_hidden), n(C)
+    return sd
 
 
 def interpolate_pos_embed(cfg: VitConfig, pos_embed: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
@@ -106,7 +137,7 @@ class VitEngine:
         def up(t):
             return t.contiguous().to(dev)
 
-        g = lambda k: sd[k].detach().float().cpu()  # noqa: E731
+        g = lambda k: sd[k].detach().float()  # noqa: E731  (packing runs on whatever device the checkpoint is on)
         w = {}
         # patch embed: the three input channels are identical copies (vit_dataset.py:117-118) -> sum the kernel
         # over channels (exact in real arithmetic), K = 196 padded to 256
@@ -140,8 +171,8 @@ class VitEngine:
             Hd, Hp = cfg.ffn_hidden, self.hid_pad
             if cfg.ffn == "swiglu":
                 w12, b12 = g(p + "mlp.w12.weight"), g(p + "mlp.w12.bias")
-                a_w, b_w = torch.zeros(Hp, C), torch.zeros(Hp, C)
-                a_b, b_b = torch.zeros(Hp), torch.zeros(Hp)
+                a_w, b_w = torch.zeros(Hp, C, device=w12.device), torch.zeros(Hp, C, device=w12.device)
+                a_b, b_b = torch.zeros(Hp, device=w12.device), torch.zeros(Hp, device=w12.device)
                 a_w[:Hd], b_w[:Hd], a_b[:Hd], b_b[:Hd] = w12[:Hd], w12[Hd:], b12[:Hd], b12[Hd:]
                 # interleave in blocks of 8 so one lane's 16 accumulators are 8 gates + their 8 values (EpiSwiGLU)
                 inter_w = torch.stack([a_w.reshape(-1, 8, C), b_w.reshape(-1, 8, C)], dim=1).reshape(2 * Hp, C)

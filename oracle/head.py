@@ -100,3 +100,26 @@ def rescaled_init_(head: nn.Module, seed: int, out_gain: float = 2.0) -> None:
         with torch.no_grad():
             m.weight.normal_(0.0, math.sqrt(gain / fan_in), generator=g)
             m.bias.normal_(0.0, 0.05, generator=g)
+
+
+@torch.inference_mode()
+def forward_volume_bf16_storage(head: CryoVITHead, x: Tensor) -> Tensor:
+    """The same network with every inter-layer activation and every GEMM-side weight rounded to bf16 (fp32 math
+    inside a layer, fp32 GroupNorm statistics, fp32 last conv) -- i.e. what a bf16-storage implementation computes
+    when its arithmetic is exact.  Separates "kernel is wrong" from "bf16 storage differs from fp32" in the tests."""
+    import torch.nn.functional as F
+
+    def bf(t):
+        return t.to(torch.bfloat16).float()
+
+    L = head.layers
+    a = bf(F.gelu(F.conv3d(bf(x), bf(L[0].weight), L[0].bias)))
+    for blk in list(L)[2:]:
+        gn, c1, c2, ct = blk.layers[0], blk.layers[1], blk.layers[3], blk.layers[5]
+        a = bf(F.group_norm(a, gn.num_groups, gn.weight, gn.bias, gn.eps))
+        a = bf(F.gelu(F.conv3d(a, bf(c1.weight), c1.bias, padding="same", dilation=c1.dilation)))
+        a = bf(F.gelu(F.conv3d(a, bf(c2.weight), c2.bias, padding="same", dilation=c2.dilation)))
+        a = bf(F.gelu(F.conv_transpose3d(a, bf(ct.weight), ct.bias, stride=(1, 2, 2))))
+    o0, o2 = head.output_layer[0], head.output_layer[2]
+    a = bf(F.gelu(F.conv3d(a, bf(o0.weight), o0.bias, padding="same")))
+    return torch.clip(F.conv3d(a, o2.weight, o2.bias, padding="same"), -5.0, 5.0)
