@@ -11,6 +11,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libcryovit_hip.so"
 
 EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT = range(7)
+DICE_BLOCKS = 4096  # CVX_DICE_BLOCKS
 
 c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
 
@@ -55,8 +56,8 @@ SIGNATURES = {
     "cvx_im2col_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "cvx_features_to_channels_last": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "cvx_groupnorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
-    "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                    c_void_p]),
+    "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                    c_int, c_void_p]),
     "cvx_dice_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
 }
 

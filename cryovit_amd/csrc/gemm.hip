@@ -1,7 +1,9 @@
 // Dense / implicit-GEMM launchers and fused epilogues (gfx950).  See gemm_core.h for the tile kernel.
 #include "gemm_core.h"
+#include "gemm256.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
+#include <stdlib.h>
 
 namespace cvx {
 
@@ -239,6 +241,41 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_conv3_nreg(const uint16_t* in,
     gemm_tile_body<Cfg>(ldr, ldl, epi, nk, (long)tr * Cfg::BR, (long)tl * Cfg::BL, smem);
 }
 
+// 256x256 phase-pipelined tile (gemm256.h): NREG (R = weights) and MREG (R = activations) orientations
+template <class Epi>
+__global__ __launch_bounds__(G256_THREADS) void k_gemm256_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
+                                                                int tiles_n, int tiles_m, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tr, tl;
+    tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
+    gemm256_body(Wt, ldw, A, lda, nk, (long)tr * 256, (long)tl * 256, epi, smem);
+}
+template <class Epi>
+__global__ __launch_bounds__(G256_THREADS) void k_gemm256_mreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
+                                                                int tiles_n, int tiles_m, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tr, tl;
+    tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tr, tl);
+    gemm256_body(A, lda, Wt, ldw, nk, (long)tr * 256, (long)tl * 256, epi, smem);
+}
+
+static bool use_gemm256(long M, long Npad, long Kpad) {
+    static const bool off = getenv("CVX_NO_GEMM256") != nullptr;  // A/B switch for benchmarking the two tile kernels
+    return !off && Npad % 256 == 0 && Kpad % BK == 0 && Kpad / BK >= 4 && M >= 1024;
+}
+
+template <class Epi, bool MREG>
+static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad, const Epi& epi,
+                      hipStream_t st) {
+    const int tiles_n = (int)(Npad / 256), tiles_m = (int)((M + 255) / 256);
+    void (*k)(const uint16_t*, long, const uint16_t*, long, int, int, int, Epi);
+    if constexpr (MREG) k = k_gemm256_mreg<Epi>; else k = k_gemm256_nreg<Epi>;
+    CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(G256_THREADS), G256_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / BK),
+                       tiles_n, tiles_m, epi);
+    return cvx_check_launch();
+}
+
 template <class Cfg, class Epi>
 static int launch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad,
                        const Epi& epi, hipStream_t st) {
@@ -254,6 +291,7 @@ template <class Epi>
 static int dispatch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad,
                          const Epi& epi, hipStream_t st) {
     if (Kpad % BK) return cvx_fail("gemm: K must be padded to a multiple of 64");
+    if (use_gemm256(M, Npad, Kpad)) return launch_256<Epi, false>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 128 == 0) return launch_nreg<TileCfg<128, 128, 2>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 64 == 0) return launch_nreg<TileCfg<64, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 32 == 0) return launch_nreg<TileCfg<32, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
@@ -294,6 +332,8 @@ extern "C" int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t st) {
         case CVX_EPI_SWIGLU: {
             if (d->n_pad % 128) return cvx_fail("gemm: SwiGLU needs N padded to 128");
             EpiSwiGLU e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
+            if (use_gemm256(d->m, d->n_pad, d->k_pad))
+                return launch_256<EpiSwiGLU, false>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
             return launch_nreg<TileCfg<128, 128, 2>>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_RESID: {
@@ -307,6 +347,8 @@ extern "C" int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t st) {
         case CVX_EPI_VT: {
             if (d->n_pad % 128 || d->k_pad % BK) return cvx_fail("gemm: V^T epilogue needs N padded to 128, K to 64");
             EpiVT e{(uint16_t*)d->out, d->bias, d->heads, d->ntp, d->kp, d->m, d->n};
+            if (use_gemm256(d->m, d->n_pad, d->k_pad))
+                return launch_256<EpiVT, true>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
             using Cfg = TileCfg<128, 128, 2>;
             const int tiles_n = (int)(d->n_pad / Cfg::BL), tiles_m = (int)((d->m + Cfg::BR - 1) / Cfg::BR);
             auto k = k_gemm_mreg<Cfg, EpiVT>;

@@ -7,18 +7,24 @@
 
 namespace cvx {
 
+// Persistent-style grid: each block walks tiles of 64(x) x 4(y) voxels; Dice partial sums stay in registers and
+// leave the block as ONE row of `partials` (no same-address atomics: 1.5 M of them cost 19 ms on this volume).
 __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ in, const float* __restrict__ w /*[27][8]*/,
                                                    float bias, float* __restrict__ logits, float* __restrict__ probs,
-                                                   const int8_t* __restrict__ labels, float* __restrict__ dice, int D, int H,
-                                                   int W) {
+                                                   const int8_t* __restrict__ labels, float* __restrict__ partials, int D, int H,
+                                                   int W, int tiles_x, int tiles_y, long ntiles) {
     __shared__ float sw[27 * 8];
+    __shared__ float red[3][4];
     for (int i = threadIdx.x; i < 27 * 8; i += 256) sw[i] = w[i];
     __syncthreads();
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int z = blockIdx.z;
     float inter = 0.f, ysum = 0.f, psum = 0.f;
-    if (x < W && y < H) {
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x);
+        const long t2 = tile / tiles_x;
+        const int ty = (int)(t2 % tiles_y), z = (int)(t2 / tiles_y);
+        const int x = tx * 64 + (threadIdx.x & 63);
+        const int y = ty * 4 + (threadIdx.x >> 6);
+        if (x >= W || y >= H) continue;
         float acc = bias;
 #pragma unroll
         for (int kz = 0; kz < 3; ++kz) {
@@ -50,17 +56,30 @@ __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ 
             const int lab = labels[v];
             if (lab > -1) {                                          // base_model.py:99
                 const float ph = p < 0.5f ? 0.f : 1.f;               // metrics.py:38
-                inter = (float)lab * ph; ysum = (float)lab; psum = ph;
+                inter += (float)lab * ph; ysum += (float)lab; psum += ph;
             }
         }
     }
     if (labels) {
         inter = wave_sum(inter); ysum = wave_sum(ysum); psum = wave_sum(psum);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&dice[0], inter);
-            atomicAdd(&dice[1], ysum);
-            atomicAdd(&dice[2], psum);
-        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[0][wv] = inter; red[1][wv] = ysum; red[2][wv] = psum; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            partials[(long)blockIdx.x * 3 + threadIdx.x] =
+                (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
+}
+
+// fixed-order (bitwise reproducible) reduction of the per-block Dice partials: dice[k] += sum_b partials[b][k]
+__global__ __launch_bounds__(64) void k_dice_finalize(const float* __restrict__ partials, int nblk, float* __restrict__ dice) {
+    const int lane = threadIdx.x;
+    for (int k = 0; k < 3; ++k) {
+        double s = 0.0;
+        for (int b = lane; b < nblk; b += 64) s += (double)partials[(long)b * 3 + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) dice[k] += (float)s;
     }
 }
 
@@ -88,12 +107,17 @@ __global__ __launch_bounds__(256) void k_dice(const float* __restrict__ probs, c
 using namespace cvx;
 
 extern "C" int cvx_conv3_out_fused(const void* in, const float* w, float bias, float* logits, float* probs,
-                                   const int8_t* labels, float* dice, int D, int H, int W, hipStream_t st) {
+                                   const int8_t* labels, float* dice, float* scratch, int D, int H, int W, hipStream_t st) {
     if (D <= 0 || H <= 0 || W <= 0) return 0;
-    if (labels && !dice) return cvx_fail("conv3_out: labels given without a dice accumulator");
-    if (D > 65535 || (H + 3) / 4 > 65535) return cvx_fail("conv3_out: volume exceeds grid limits");
-    dim3 grid((W + 63) / 64, (H + 3) / 4, D);
-    hipLaunchKernelGGL(k_conv3_out, grid, dim3(256), 0, st, (const uint16_t*)in, w, bias, logits, probs, labels, dice, D, H, W);
+    if (labels && (!dice || !scratch)) return cvx_fail("conv3_out: labels need a dice accumulator and a scratch buffer");
+    const int tiles_x = (W + 63) / 64, tiles_y = (H + 3) / 4;
+    const long ntiles = (long)tiles_x * tiles_y * D;
+    const int nblk = (int)(ntiles < CVX_DICE_BLOCKS ? ntiles : CVX_DICE_BLOCKS);
+    hipLaunchKernelGGL(k_conv3_out, dim3(nblk), dim3(256), 0, st, (const uint16_t*)in, w, bias, logits, probs, labels, scratch, D,
+                       H, W, tiles_x, tiles_y, ntiles);
+    int rc = cvx_check_launch();
+    if (rc || !labels) return rc;
+    hipLaunchKernelGGL(k_dice_finalize, dim3(1), dim3(64), 0, st, scratch, nblk, dice);
     return cvx_check_launch();
 }
 

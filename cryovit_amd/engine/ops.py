@@ -130,10 +130,18 @@ def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tens
                                          G, eps, _stream()), "cvx_groupnorm_bf16")
 
 
+_dice_scratch = {}
+
+
 def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs, labels, dice, *, D: int, H: int, W: int) -> None:
     _dev_check(x, w, logits, probs, labels, dice)
-    check(_lib.load().cvx_conv3_out_fused(x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), _p(labels), _p(dice), D,
-                                          H, W, _stream()), "cvx_conv3_out_fused")
+    scratch = None
+    if labels is not None:
+        scratch = _dice_scratch.get(x.device)
+        if scratch is None:
+            scratch = _dice_scratch[x.device] = torch.zeros(3 * _lib.DICE_BLOCKS, dtype=torch.float32, device=x.device)
+    check(_lib.load().cvx_conv3_out_fused(x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), _p(labels), _p(dice),
+                                          _p(scratch), D, H, W, _stream()), "cvx_conv3_out_fused")
 
 
 def dice_sums(probs: torch.Tensor, labels: torch.Tensor, dice: torch.Tensor, thr: float = 0.5) -> None:

@@ -321,3 +321,73 @@ def test_conv3_out_fused_and_dice(gpu, gold):
     ops.dice_sums(torch.from_numpy(g["preds"]).to(gpu), torch.from_numpy(g["labels"]).to(gpu), d2, 0.5)
     i, sy, sp = d2.cpu().tolist()
     assert abs(2 * i / (sy + sp + 1e-3) - float(g["dice"])) < 1e-6
+
+
+# ---- the 256x256 phase-pipelined tile (gemm256.h): every epilogue at shapes that dispatch to it ---------------------------
+@pytest.mark.parametrize("M,N,K", [(1029 * 2 + 7, 512, 256), (3000, 256, 1536), (2048, 1536, 4096)])
+def test_gemm256_bf16_and_resid(gpu, M, N, K):
+    from cryovit_amd._lib import EPI_BF16, EPI_RESID
+    from cryovit_amd.engine import ops
+
+    a, w, b, gm = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=K**-0.5), rnd(N, seed=63), rnd(N, seed=64)
+    A, Wd = padded_bf16(a, ops.alloc_rows(M), K, gpu), padded_bf16(w, N, K, gpu)
+    ref = bf(a).float() @ bf(w).float().T + b
+    out = torch.full((ops.alloc_rows(M), N), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_BF16, A, Wd, out, b.to(gpu), m=M, n=N)
+    got = out[:M].float().cpu()
+    assert torch.allclose(got, ref, atol=2e-2, rtol=1e-2), float((got - ref).abs().max())
+    assert torch.all(out[M:].float() == 7.0)
+    x0 = rnd(M, N, seed=65)
+    x = torch.zeros(ops.alloc_rows(M), N, device=gpu)
+    x[:M] = x0.to(gpu)
+    ops.gemm(EPI_RESID, A, Wd, x, b.to(gpu), m=M, n=N, gamma=gm.to(gpu))
+    assert torch.allclose(x[:M].cpu(), x0 + gm * ref, atol=2e-4, rtol=1e-4)
+    # race screen: the pipeline's waits/barriers are hand-counted -- repeated launches must be bit-identical
+    outs = []
+    for _ in range(8):
+        o = torch.zeros(ops.alloc_rows(M), N, dtype=torch.bfloat16, device=gpu)
+        ops.gemm(EPI_BF16, A, Wd, o, b.to(gpu), m=M, n=N)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_gemm256_swiglu_vt_patch(gpu):
+    from cryovit_amd._lib import EPI_PATCH, EPI_SWIGLU, EPI_VT
+    from cryovit_amd.engine import ops
+
+    # SwiGLU: N = 2*Hp = 1024
+    M, K, Hd = 1500, 256, 512
+    a, w12, b12 = rnd(M, K, seed=66), rnd(2 * Hd, K, seed=67, scale=K**-0.5), rnd(2 * Hd, seed=68)
+    iw = torch.stack([w12[:Hd].reshape(-1, 8, K), w12[Hd:].reshape(-1, 8, K)], 1).reshape(2 * Hd, K)
+    ib = torch.stack([b12[:Hd].reshape(-1, 8), b12[Hd:].reshape(-1, 8)], 1).reshape(2 * Hd)
+    A = padded_bf16(a, ops.alloc_rows(M), K, gpu)
+    out = torch.zeros(ops.alloc_rows(M), Hd, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_SWIGLU, A, bf(iw).to(gpu), out, ib.to(gpu), m=M, n=2 * Hd)
+    h = bf(a).float() @ bf(w12).float().T + b12
+    ref = F.silu(h[:, :Hd]) * h[:, Hd:]
+    assert torch.allclose(out[:M].float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    # V^T (MREG orientation): 4 heads -> N = 256
+    b_, heads, nt = 5, 4, 261
+    ntp, kp, C = ops.round_up(nt, 8), 320, heads * 64
+    Mv = b_ * ntp
+    av, wv, bv = rnd(Mv, K, seed=69), rnd(C, K, seed=70, scale=K**-0.5), rnd(C, seed=71)
+    vt = torch.zeros(b_, heads, 64, kp, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_VT, padded_bf16(av, ops.alloc_rows(Mv), K, gpu), padded_bf16(wv, C, K, gpu), vt, bv.to(gpu), m=Mv, n=C, heads=heads,
+             ntp=ntp, kp=kp, ldc=0)
+    v = (bf(av).float() @ bf(wv).float().T + bv).reshape(b_, ntp, heads, 64).permute(0, 2, 3, 1)
+    got = vt.float().cpu()
+    assert torch.allclose(got[..., :ntp], v, atol=2e-2, rtol=1e-2) and torch.all(got[..., ntp:] == 0)
+    # patch embed into the token stream: C = 256
+    bp, npatch, Cp, n_reg = 5, 256, 256, 4
+    ntk = npatch + 5
+    ntpp = ops.round_up(ntk, 8)
+    ap, wp_, bias = rnd(bp * npatch, 196, seed=72), rnd(Cp, 196, seed=73, scale=196**-0.5), rnd(Cp, seed=74)
+    pos = rnd(1 + npatch, Cp, seed=75)
+    x = torch.zeros(ops.alloc_rows(bp * ntpp), Cp, device=gpu)
+    ops.gemm(EPI_PATCH, padded_bf16(ap, ops.alloc_rows(bp * npatch), 256, gpu), padded_bf16(wp_, Cp, 256, gpu), x, bias.to(gpu),
+             m=bp * npatch, n=Cp, pos=pos.to(gpu), npatch=npatch, ntp=ntpp, tok0=1 + n_reg)
+    pe = (bf(ap).float() @ bf(wp_).float().T + bias).reshape(bp, npatch, Cp) + pos[1:]
+    got = x[: bp * ntpp].cpu().reshape(bp, ntpp, Cp)
+    assert torch.allclose(got[:, 1 + n_reg : ntk], pe, atol=1e-4, rtol=1e-4)
+    assert torch.all(got[:, :1 + n_reg] == 0) and torch.all(got[:, ntk:] == 0)
