@@ -45,6 +45,8 @@ SIGNATURES = {
     "cvx_last_error": (C.c_char_p, []),
     "cvx_version": (c_int, []),
     "cvx_device_arch": (c_int, [C.c_char_p, c_int]),
+    "cvx_set_option": (c_int, [C.c_char_p, c_int]),
+    "cvx_debug_read_gemm256": (c_int, [c_void_p]),
     "cvx_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "cvx_conv3d_bf16": (c_int, [C.POINTER(Conv3dDesc), c_void_p]),
     "cvx_layernorm_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
@@ -100,3 +102,7 @@ def device_arch() -> str:
     buf = C.create_string_buffer(128)
     check(load().cvx_device_arch(buf, 128), "cvx_device_arch")
     return buf.value.decode()
+
+
+def set_option(name: str, value: int) -> None:
+    check(load().cvx_set_option(name.encode(), int(value)), "cvx_set_option")

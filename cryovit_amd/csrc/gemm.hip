@@ -1,9 +1,11 @@
 // Dense / implicit-GEMM launchers and fused epilogues (gfx950).  See gemm_core.h for the tile kernel.
 #include "gemm_core.h"
 #include "gemm256.h"
+#include "gemm4w.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace cvx {
 
@@ -242,34 +244,71 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_conv3_nreg(const uint16_t* in,
 }
 
 // 256x256 phase-pipelined tile (gemm256.h): NREG (R = weights) and MREG (R = activations) orientations
-template <class Epi>
+template <class Epi, int VARIANT>
 __global__ __launch_bounds__(G256_THREADS) void k_gemm256_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
                                                                 int tiles_n, int tiles_m, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tr, tl;
     tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
-    gemm256_body(Wt, ldw, A, lda, nk, (long)tr * 256, (long)tl * 256, epi, smem);
+    gemm256_body<VARIANT>(Wt, ldw, A, lda, nk, (long)tr * 256, (long)tl * 256, epi, smem);
 }
-template <class Epi>
+template <class Epi, int VARIANT>
 __global__ __launch_bounds__(G256_THREADS) void k_gemm256_mreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
                                                                 int tiles_n, int tiles_m, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tr, tl;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tr, tl);
-    gemm256_body(A, lda, Wt, ldw, nk, (long)tr * 256, (long)tl * 256, epi, smem);
+    gemm256_body<VARIANT>(A, lda, Wt, ldw, nk, (long)tr * 256, (long)tl * 256, epi, smem);
+}
+
+// tuning switches (cvx_set_option): A/B the tile kernels and pipeline schedules inside ONE process
+static int g_use_gemm256 = 1, g_gemm256_variant = 5;
+
+template <class Epi, bool MREG>
+__global__ __launch_bounds__(G4W_THREADS) void k_gemm4w(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nks,
+                                                         int tiles_n, int tiles_m, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tr, tl;
+    if constexpr (MREG) {
+        tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tr, tl);
+        gemm4w_body<0>(A, lda, Wt, ldw, nks, (long)tr * 256, (long)tl * 256, epi, smem);
+    } else {
+        tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
+        gemm4w_body<0>(Wt, ldw, A, lda, nks, (long)tr * 256, (long)tl * 256, epi, smem);
+    }
 }
 
 static bool use_gemm256(long M, long Npad, long Kpad) {
-    static const bool off = getenv("CVX_NO_GEMM256") != nullptr;  // A/B switch for benchmarking the two tile kernels
-    return !off && Npad % 256 == 0 && Kpad % BK == 0 && Kpad / BK >= 4 && M >= 1024;
+    return g_use_gemm256 && Npad % 256 == 0 && Kpad % BK == 0 && Kpad / BK >= 4 && M >= 1024;
 }
 
 template <class Epi, bool MREG>
 static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad, const Epi& epi,
                       hipStream_t st) {
     const int tiles_n = (int)(Npad / 256), tiles_m = (int)((M + 255) / 256);
+    if (g_use_gemm256 == 2) {  // one-wave-per-SIMD tile (gemm4w.h)
+        auto k4 = k_gemm4w<Epi, MREG>;
+        CVX_HIP(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, G4W_LDS_BYTES));
+        hipLaunchKernelGGL(k4, dim3(tiles_n * tiles_m), dim3(G4W_THREADS), G4W_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / G4W_KS),
+                           tiles_n, tiles_m, epi);
+        return cvx_check_launch();
+    }
+    const int variant = g_gemm256_variant;
     void (*k)(const uint16_t*, long, const uint16_t*, long, int, int, int, Epi);
-    if constexpr (MREG) k = k_gemm256_mreg<Epi>; else k = k_gemm256_nreg<Epi>;
+    if constexpr (MREG) {
+        k = k_gemm256_mreg<Epi, 0>;
+    } else {
+        switch (variant) {
+            case 1: k = k_gemm256_nreg<Epi, 1>; break;
+            case 5: k = k_gemm256_nreg<Epi, 5>; break;
+            case 6: k = k_gemm256_nreg<Epi, 6>; break;
+            case 20: k = k_gemm256_nreg<Epi, 20>; break;
+            case 10: k = k_gemm256_nreg<Epi, 10>; break;
+            case 11: k = k_gemm256_nreg<Epi, 11>; break;
+            case 12: k = k_gemm256_nreg<Epi, 12>; break;
+            default: k = k_gemm256_nreg<Epi, 0>; break;
+        }
+    }
     CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
     hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(G256_THREADS), G256_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / BK),
                        tiles_n, tiles_m, epi);
@@ -314,6 +353,23 @@ static int launch_conv3(const cvx_conv3d_desc& d, const Epi& epi, hipStream_t st
 }  // namespace cvx
 
 using namespace cvx;
+
+extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
+    CVX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvx::g_gemm256_dbg), sizeof(unsigned long long) * 32));
+    return 0;
+}
+
+extern "C" int cvx_set_option(const char* name, int value) {
+    if (!name) return cvx_fail("set_option: null name");
+    if (!strcmp(name, "use_gemm256")) g_use_gemm256 = value;
+    else if (!strcmp(name, "gemm256_variant")) g_gemm256_variant = value;
+    else if (!strcmp(name, "tile_group_l")) {
+        if (value < 1) return cvx_fail("set_option: tile_group_l must be >= 1");
+        CVX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cvx::g_tile_group_l), &value, sizeof(int)));
+    }
+    else return cvx_fail("set_option: unknown option");
+    return 0;
+}
 
 extern "C" int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t st) {
     if (!d) return cvx_fail("gemm: null descriptor");

@@ -10,36 +10,51 @@
 //             2: R-hi                                     3: L-hi
 //     and one K tile is computed in four phases of 16 MFMAs:  (R-lo,L-lo) (R-hi,L-lo) (R-hi,L-hi) (R-lo,L-hi).
 //     Fragments stay in registers after their phase, so half-tile q is READ only in phase rd(q) in {q-1, q}.
-//   * LDS holds a ring of 8 half-tiles (2 K tiles, 128 KiB).  Phase g issues the LDS-DMA of half-tile g+A (A = 5):
-//     3-4 half-tiles are always in flight ACROSS barriers behind a counted s_waitcnt vmcnt(6/8) -- never vmcnt(0)
-//     in the steady state.
+//   * LDS holds a ring of 8 half-tiles (2 K tiles, 128 KiB).  Every half-tile q is READ exactly once, into registers, in
+//     the load segment of phase q-1 (R-lo of the NEXT K tile is read during phase 3, into the register set the dead R-hi
+//     fragments just vacated -- the two R register sets swap roles every K tile).  Phase g issues the LDS-DMA of
+//     half-tile g+7: FIVE half-tiles (80 KiB) are always in flight across barriers behind a counted
+//     s_waitcnt vmcnt(10) -- the kernel is DMA-latency bound (64 KiB per 2048 MFMA cycles per CU against ~1 us of
+//     loaded L2/HBM latency), so bytes in flight, not issue slots, set its speed.
 //   * Two barriers per phase split it into a LOAD segment (ds_read fragments, issue DMA, counted wait) and an MFMA
 //     segment.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA segment while
 //     its partner is in its load segment: the matrix pipe never waits for LDS latency.
-//   Hazards (one barrier of stagger included):
-//     RAW  half-tile q is waited for (every wave, its own DMA pieces) at the END of the load segment of phase
-//          rd(q)-1, i.e. ahead of a barrier that every reader passes before its first ds_read of q.
-//     WAR  slot of q is rewritten by DMA(q+8) issued in load segment q+3 >= rd(q)+3: the late group's reads of q
-//          completed (lgkmcnt(0) opens its MFMA segment) two barriers earlier.
+//   Hazards (barrier instances I_k; group 0 load segment g = (I_2g+1, I_2g+2), group 1 = (I_2g+2, I_2g+3)):
+//     RAW  half-tile q (read in phase q-1) is waited for by EVERY wave (its own DMA pieces) at the end of its load
+//          segment of phase q-2, i.e. before I_2q-1 at the latest; the earliest read of q is after I_2q-1.
+//     WAR  the slot of q is rewritten by DMA(q+8), issued in load segment q+1 (after I_2q+3); the late group's reads of
+//          q completed (lgkmcnt(0) opens its MFMA segment q-1) before I_2q+2.
 #pragma once
 #include "gemm_core.h"
+#include <type_traits>
 
 namespace cvx {
 
 constexpr int G256_THREADS = 512;
 constexpr int G256_HALF_BYTES = 128 * 128;            // 128 rows x 64 bf16
 constexpr int G256_LDS_BYTES = 8 * G256_HALF_BYTES;   // ring of 8 half-tiles
-constexpr int G256_AHEAD = 5;
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else static_assert(N == 0, "unsupported count");
+// diagnostic build only (VARIANT 20): per-wave cycle sums of the four parts of a phase, block 0 -> g_gemm256_dbg
+__device__ unsigned long long g_gemm256_dbg[8 * 4];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
 }
 
-template <class Epi>
+// wait until at most `pending` half-tiles (2 LDS-DMA instructions each) of this wave are still in flight
+__device__ __forceinline__ void wait_halftiles(int pending) {
+    switch (pending) {  // wave-uniform
+        case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int VARIANT, class Epi>
 __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, long ldr, const uint16_t* __restrict__ Lmat,
                                              long ldl, int nk, long r0, long l0, const Epi& epi, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -64,12 +79,18 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     const uint16_t* Rb = Rmat + r0 * ldr;
     const uint16_t* Lb = Lmat + l0 * ldl;
 
+    // timing-only ablations (results are garbage): 10 = no DMA in the loop, 11 = DMA always from K tile 0 (L2-resident),
+    // 12 = no fragment reads in the loop
+    constexpr bool ABL_NO_DMA = VARIANT == 10, ABL_SAME_K = VARIANT == 11, ABL_NO_READ = VARIANT == 12;
     auto issue = [&](int q) {  // half-tile q -> ring slot q & 7
-        const int kt = q >> 2, kind = q & 3;
+        const int kt = ABL_SAME_K ? 0 : (q >> 2), kind = q & 3;
         char* dst = smem + (q & 7) * G256_HALF_BYTES + wave * 1024;
-        const uint16_t* src = ((kind & 1) ? Lb : Rb) + kt * BK;
-        const uint32_t o0 = (kind & 1) ? offL[kind >> 1][0] : offR[kind >> 1][0];
-        const uint32_t o1 = (kind & 1) ? offL[kind >> 1][1] : offR[kind >> 1][1];
+        // slot order inside a K tile: variants 0-5: R-lo, L-lo, R-hi, L-hi;  variant 6: R-lo, R-hi, L-lo, L-hi
+        const bool isL = VARIANT == 6 ? (kind >= 2) : (kind & 1);
+        const int half = VARIANT == 6 ? (kind & 1) : (kind >> 1);
+        const uint16_t* src = (isL ? Lb : Rb) + kt * BK;
+        const uint32_t o0 = isL ? offL[half][0] : offR[half][0];
+        const uint32_t o1 = isL ? offL[half][1] : offR[half][1];
         glds16(src + o0, dst);
         glds16(src + o1, dst + G256_THREADS * 16);
     };
@@ -86,6 +107,67 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    [[maybe_unused]] unsigned long long dbg_load = 0, dbg_lbar = 0, dbg_mma = 0, dbg_mbar = 0;
+    constexpr bool STAMP = VARIANT == 20;
+    if constexpr (VARIANT == 6) {
+    // ---- variant 6: TWO phases of 32 MFMAs per K tile (half the barriers): A = (R, L-lo), B = (R, L-hi); the DMA runs
+    //      exactly one K tile ahead (R halves issued in phase A, L halves in phase B) ----
+    bf16x8 rlo[2][2], rhi[2][2], lf[4][2];
+    auto read_r = [&](bf16x8 (&dst)[2][2], const char* half) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dst[f][ks] = *(const bf16x8*)(half + ((foR + f * 2048) ^ (ks << 6)));
+    };
+    auto read_l = [&](const char* half) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) lf[f][ks] = *(const bf16x8*)(half + ((foL + f * 2048) ^ (ks << 6)));
+    };
+    auto mma32 = [&](int b0) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a][b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a < 2 ? rlo[a][ks] : rhi[a - 2][ks], lf[b][ks],
+                                                                              acc[a][b0 + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    for (int q = 0; q < 4; ++q) issue(q);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // R-lo, R-hi, L-lo of K tile 0 landed
+    __builtin_amdgcn_s_barrier();
+    if (wl == 1) __builtin_amdgcn_s_barrier();
+    auto ktile = [&](int t, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const char* st = smem + (t & 1) * 4 * G256_HALF_BYTES;
+        const int g = 4 * t;
+        read_r(rlo, st);
+        read_r(rhi, st + G256_HALF_BYTES);
+        read_l(st + 2 * G256_HALF_BYTES);
+        if (STEADY || g + 4 < total) { issue(g + 4); issue(g + 5); }
+        if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mma32(0);
+        __builtin_amdgcn_s_barrier();
+        read_l(st + 3 * G256_HALF_BYTES);
+        if (STEADY || g + 6 < total) { issue(g + 6); issue(g + 7); }
+        if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mma32(4);
+        __builtin_amdgcn_s_barrier();
+    };
+    {
+        int t = 0;
+        for (; t < nk - 1; ++t) ktile(t, std::true_type{});
+        for (; t < nk; ++t) ktile(t, std::false_type{});
+    }
+    if (wl == 0) __builtin_amdgcn_s_barrier();
+    } else if constexpr (VARIANT == 0 || VARIANT == 4 || VARIANT == 5 || VARIANT >= 10) {
+    // ---- variants 0/4/5: reads at rd(q) in {q-1,q}, 3-4 half-tiles in flight (A = 5) ----
     bf16x8 rlo[2][2], rhi[2][2], lf[4][2];  // [frag][k-step]
 
     auto read_r = [&](bf16x8 (&dst)[2][2], const char* half) {
@@ -114,47 +196,173 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 
     // ---- prologue: half-tiles 0..A-1 in flight, 0 and 1 landed ----
 #pragma unroll
-    for (int q = 0; q < G256_AHEAD; ++q)
+    for (int q = 0; q < 5; ++q)
         if (q < total) issue(q);
-    if (total > G256_AHEAD) wait_vmcnt<6>(); else wait_vmcnt<0>();
+    if (total > 5) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wl == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 run one barrier behind
 
-    for (int t = 0; t < nk; ++t) {
+    // one K tile.  STEADY: all four DMA issues exist -> unconditional issue + exact counted waits (no branches).
+    // ISSUE_IN_MMA: the DMA is issued from the MFMA segment (in the issue gaps of the wave's own MFMAs) instead of the
+    // load segment, which is the critical one (it competes for issue slots with the partner wave's MFMA stream).
+    constexpr bool ISSUE_IN_MMA = (VARIANT == 5);
+    auto ktile = [&](int t, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
         const char* st = smem + (t & 1) * 4 * G256_HALF_BYTES;
         const int g = 4 * t;
-        const bool steady = g + 3 + G256_AHEAD < total;  // all four issues of this K tile exist: counted waits are exact
+        [[maybe_unused]] unsigned long long t0 = 0;
+        if constexpr (STAMP) t0 = stamp();
+        auto do_issue = [&](int q) {
+            if constexpr (ABL_NO_DMA) return;
+            if (STEADY || q < total) issue(q);
+        };
+        auto do_wait = [&](auto n_tag) {
+            constexpr int N = decltype(n_tag)::value;
+            if constexpr (!STEADY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        };
+        using W6 = std::integral_constant<int, ISSUE_IN_MMA ? 4 : 6>;
+        using W8 = std::integral_constant<int, ISSUE_IN_MMA ? 6 : 8>;
         // ---- phase 0: (R-lo, L-lo) ----
-        read_r(rlo, st);
-        read_l(st + G256_HALF_BYTES);
-        if (g + G256_AHEAD < total) issue(g + G256_AHEAD);
-        if (steady) wait_vmcnt<6>(); else wait_vmcnt<0>();
+        if (!ABL_NO_READ || t == 0) {
+            read_r(rlo, st);
+            read_l(st + G256_HALF_BYTES);
+        }
+        if constexpr (!ISSUE_IN_MMA) do_issue(g + 5);
+        do_wait(W6{});
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_load += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_lbar += t1 - t0; t0 = t1; }
+        if constexpr (ISSUE_IN_MMA) do_issue(g + 5);
         mma(rlo, 0, 0);
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mma += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mbar += t1 - t0; t0 = t1; }
         // ---- phase 1: (R-hi, L-lo) ----
-        read_r(rhi, st + 2 * G256_HALF_BYTES);
-        if (g + 1 + G256_AHEAD < total) issue(g + 1 + G256_AHEAD);
-        if (steady) wait_vmcnt<6>(); else wait_vmcnt<0>();
+        if (!ABL_NO_READ || t == 0) read_r(rhi, st + 2 * G256_HALF_BYTES);
+        if constexpr (!ISSUE_IN_MMA) do_issue(g + 6);
+        do_wait(W6{});
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_load += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_lbar += t1 - t0; t0 = t1; }
+        if constexpr (ISSUE_IN_MMA) do_issue(g + 6);
         mma(rhi, 2, 0);
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mma += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mbar += t1 - t0; t0 = t1; }
         // ---- phase 2: (R-hi, L-hi) ----
-        read_l(st + 3 * G256_HALF_BYTES);
-        if (g + 2 + G256_AHEAD < total) issue(g + 2 + G256_AHEAD);
-        if (steady) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        if (!ABL_NO_READ || t == 0) read_l(st + 3 * G256_HALF_BYTES);
+        if constexpr (!ISSUE_IN_MMA) do_issue(g + 7);
+        do_wait(W8{});
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_load += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_lbar += t1 - t0; t0 = t1; }
+        if constexpr (ISSUE_IN_MMA) do_issue(g + 7);
         mma(rhi, 2, 4);
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mma += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mbar += t1 - t0; t0 = t1; }
         // ---- phase 3: (R-lo, L-hi) ----
-        if (g + 3 + G256_AHEAD < total) issue(g + 3 + G256_AHEAD);
-        if (steady) wait_vmcnt<6>(); else wait_vmcnt<0>();
+        if constexpr (!ISSUE_IN_MMA) do_issue(g + 8);
+        do_wait(W6{});
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_load += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_lbar += t1 - t0; t0 = t1; }
+        if constexpr (ISSUE_IN_MMA) do_issue(g + 8);
         mma(rlo, 0, 4);
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mma += t1 - t0; t0 = t1; }
         __builtin_amdgcn_s_barrier();
+        if constexpr (STAMP) { const auto t1 = stamp(); dbg_mbar += t1 - t0; t0 = t1; }
+    };
+    {   // (a per-tile runtime choice between the two instantiations makes hipcc spill the accumulators: keep two loops)
+        int t = 0;
+        for (; t < nk - 2; ++t) ktile(t, std::true_type{});
+        for (; t < nk; ++t) ktile(t, std::false_type{});
     }
     if (wl == 0) __builtin_amdgcn_s_barrier();  // pairs with the stagger barrier of waves 4-7
 
+    } else {
+    // ---- variant 1: every half-tile read in phase q-1, AHEAD-2 half-tiles in flight ----
+    constexpr int AHEAD = VARIANT == 1 ? 7 : (VARIANT == 2 ? 6 : 5);
+    bf16x8 rx[2][2], ry[2][2], lf[4][2];  // [frag][k-step]; rx / ry swap the R-lo / R-hi roles every K tile
+
+    auto read_r = [&](bf16x8 (&dst)[2][2], const char* half) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dst[f][ks] = *(const bf16x8*)(half + ((foR + f * 2048) ^ (ks << 6)));
+    };
+    auto read_l = [&](const char* half) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) lf[f][ks] = *(const bf16x8*)(half + ((foL + f * 2048) ^ (ks << 6)));
+    };
+    auto mma = [&](const bf16x8 (&r)[2][2], int a0, int b0) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a0 + a][b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[a][ks], lf[b][ks], acc[a0 + a][b0 + b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // end of the load segment of phase g: issue half-tile g+AHEAD, then retire (own pieces of) half-tile g+2
+    auto issue_and_wait = [&](int g) {
+        if (g + AHEAD < total) issue(g + AHEAD);
+        const int last_issued = min(g + AHEAD, total - 1);
+        wait_halftiles(last_issued - (g + 2));
+        __builtin_amdgcn_s_barrier();
+    };
+    // one K tile = 4 phases; `lo` holds R-lo(t) on entry, `hi` receives R-hi(t) and then R-lo(t+1)
+    auto ktile = [&](int t, bf16x8 (&lo)[2][2], bf16x8 (&hi)[2][2]) {
+        const char* st = smem + (t & 1) * 4 * G256_HALF_BYTES;
+        const char* nx = smem + ((t + 1) & 1) * 4 * G256_HALF_BYTES;
+        const int g = 4 * t;
+        read_l(st + G256_HALF_BYTES);            // phase 0: L-lo(t)
+        issue_and_wait(g);
+        mma(lo, 0, 0);
+        __builtin_amdgcn_s_barrier();
+        read_r(hi, st + 2 * G256_HALF_BYTES);    // phase 1: R-hi(t)
+        issue_and_wait(g + 1);
+        mma(hi, 2, 0);
+        __builtin_amdgcn_s_barrier();
+        read_l(st + 3 * G256_HALF_BYTES);        // phase 2: L-hi(t)
+        issue_and_wait(g + 2);
+        mma(hi, 2, 4);
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nk) read_r(hi, nx);          // phase 3: R-lo(t+1) into the registers R-hi(t) just vacated
+        issue_and_wait(g + 3);
+        mma(lo, 0, 4);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- prologue: half-tiles 0..A-1 in flight; 0 and 1 landed; R-lo(0) read ----
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q)
+        if (q < total) issue(q);
+    wait_halftiles(min(AHEAD - 1, total - 1) - 1);
+    __builtin_amdgcn_s_barrier();
+    read_r(rx, smem);
+    if (wl == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 run one barrier behind
+
+    for (int t = 0; t < nk; t += 2) {
+        ktile(t, rx, ry);
+        if (t + 1 < nk) ktile(t + 1, ry, rx);
+    }
+    if (wl == 0) __builtin_amdgcn_s_barrier();  // pairs with the stagger barrier of waves 4-7
+
+    }
+    if constexpr (STAMP) {
+        if (blockIdx.x == 0 && lane == 0) {
+            g_gemm256_dbg[wave * 4 + 0] = dbg_load; g_gemm256_dbg[wave * 4 + 1] = dbg_lbar;
+            g_gemm256_dbg[wave * 4 + 2] = dbg_mma; g_gemm256_dbg[wave * 4 + 3] = dbg_mbar;
+        }
+    }
     // ---- epilogue: lane group g owns 16 contiguous R rows, one L row per fragment ----
     const int gq = lane >> 4;
     const long rbase = r0 + wr * 64 + gq * 16;

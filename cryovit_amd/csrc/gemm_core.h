@@ -136,10 +136,11 @@ struct TileCfg {
 // XCD-aware, grouped tile order: blocks b and b+8 share an XCD (private L2), so each XCD gets a contiguous
 // chunk of the logical tile sequence (bijective for any grid size); inside the sequence, tiles sweep the
 // R dimension within bands of GROUP_L L-tiles so concurrently resident blocks share operand panels.
+__device__ int g_tile_group_l = 8;  // tuning knob (cvx_set_option "tile_group_l")
 __device__ __forceinline__ void tile_coords(int bid, int nblk, int tiles_r, int tiles_l, int& tr, int& tl) {
     const int q = nblk >> 3, rem = nblk & 7, xcd = bid & 7;
     const int id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    constexpr int GROUP_L = 8;
+    const int GROUP_L = g_tile_group_l;
     const int per_band = GROUP_L * tiles_r;
     const int band = id / per_band, in = id - band * per_band;
     const int l_first = band * GROUP_L;

@@ -39,6 +39,10 @@ const char* cvx_last_error(void);
 int cvx_version(void);
 /* name of the device the library would launch on ("gfx950...") or "" when no HIP device is visible */
 int cvx_device_arch(char* buf, int buflen);
+/* tuning switches for in-process A/B measurements: "use_gemm256" (0/1), "gemm256_variant" (pipeline schedule id) */
+int cvx_set_option(const char* name, int value);
+/* diagnostic: per-wave cycle sums {load, load-barrier, mma, mma-barrier} x 8 waves written by gemm256 variant 20 */
+int cvx_debug_read_gemm256(unsigned long long* out32);
 
 /* ---------------------------------------------------------------------------------------------------
  * Dense GEMM  C[M,N] = A[M,K] * W[N,K]^T, bf16 operands (K contiguous, leading dims in elements),

@@ -324,8 +324,25 @@ def test_conv3_out_fused_and_dice(gpu, gold):
 
 
 # ---- the 256x256 phase-pipelined tile (gemm256.h): every epilogue at shapes that dispatch to it ---------------------------
+@pytest.fixture
+def gemm256_variant(request):
+    """Every pipeline schedule kept in gemm256.h is parity-tested, not only the default one."""
+    from cryovit_amd import _lib
+
+    kernel, variant = request.param
+    _lib.set_option("use_gemm256", kernel)
+    _lib.set_option("gemm256_variant", variant)
+    yield request.param
+    _lib.set_option("use_gemm256", DEFAULT_GEMM[0])
+    _lib.set_option("gemm256_variant", DEFAULT_GEMM[1])
+
+
+DEFAULT_GEMM = (1, 5)  # (tile kernel: 1 = 8-wave gemm256.h, 2 = 4-wave gemm4w.h; gemm256 schedule variant)
+
+
+@pytest.mark.parametrize("gemm256_variant", [(1, 0), (1, 1), (1, 5), (1, 6), (2, 0)], indirect=True)
 @pytest.mark.parametrize("M,N,K", [(1029 * 2 + 7, 512, 256), (3000, 256, 1536), (2048, 1536, 4096)])
-def test_gemm256_bf16_and_resid(gpu, M, N, K):
+def test_gemm256_bf16_and_resid(gpu, M, N, K, gemm256_variant):
     from cryovit_amd._lib import EPI_BF16, EPI_RESID
     from cryovit_amd.engine import ops
 
@@ -352,7 +369,8 @@ def test_gemm256_bf16_and_resid(gpu, M, N, K):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
-def test_gemm256_swiglu_vt_patch(gpu):
+@pytest.mark.parametrize("gemm256_variant", [(1, 5), (2, 0)], indirect=True)
+def test_gemm256_swiglu_vt_patch(gpu, gemm256_variant):
     from cryovit_amd._lib import EPI_PATCH, EPI_SWIGLU, EPI_VT
     from cryovit_amd.engine import ops
 

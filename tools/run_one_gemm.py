@@ -1,0 +1,23 @@
+"""Launch the dominant GEMM (w12 + SwiGLU, ViT-g shape, one 128-slice batch) a few times -- target for rocprofv3 --pmc."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from cryovit_amd import _lib  # noqa: E402
+from cryovit_amd._lib import EPI_SWIGLU  # noqa: E402
+from cryovit_amd.engine import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+M, K, N = 128 * 1032, 1536, 8192
+if len(sys.argv) > 1:
+    _lib.set_option("gemm256_variant", int(sys.argv[1]))
+g = torch.Generator(device=dev).manual_seed(0)
+a = torch.randn(ops.alloc_rows(M), K, device=dev, generator=g).to(torch.bfloat16)
+w = (torch.randn(N, K, device=dev, generator=g) * K**-0.5).to(torch.bfloat16)
+bias = torch.randn(N, device=dev, generator=g)
+out = torch.zeros(ops.alloc_rows(M), N // 2, dtype=torch.bfloat16, device=dev)
+for _ in range(6):
+    ops.gemm(EPI_SWIGLU, a, w, out, bias, m=M, n=N)
+torch.cuda.synchronize()
