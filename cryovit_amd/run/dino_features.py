@@ -1,0 +1,106 @@
+"""Feature-stage runner (mirror of ``/root/reference/src/cryovit/run/dino_features.py``): same functions, same on-disk
+result, arithmetic on the HIP engine.
+
+  _dino_features   l.31-64    slices -> encoder -> float16 [C, D, H/16, W/16]
+  _save_data       l.109-153  output HDF5: ``data`` + ``labels/<leaf>`` gzip, ``dino_features`` contiguous fp16
+  _process_sample  l.156-205  enumerate records, per tomogram: features -> re-read source -> save
+  run_trainer      l.304-350  paths (incl. the inverted src/dst naming), model load, sample loop
+Multi-GPU: records of a sample are sharded over the ranks of a ``torch.distributed.run`` launch (run/sharding.py).
+"""
+
+from __future__ import annotations
+
+import csv
+import logging
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from cryovit_amd import io
+from cryovit_amd.config import instantiate, samples, tomogram_exts
+from cryovit_amd.models.encoder import load_encoder
+from cryovit_amd.run.sharding import shard_records, world_info
+
+
+@torch.inference_mode()
+def _dino_features(data: torch.Tensor, model, batch_size: int) -> np.ndarray:
+    """Patch features of one tomogram as float16 ``[C, D, H/16, W/16]`` (C-contiguous, owned by the caller).
+
+    ``data`` is either the raw volume ``[D,H,W]`` (uint8 / float32: the fused path -- resize happens on the GPU) or the
+    reference's pre-resized ``[D,3,H',W']`` float32 tensor (protocol path through ``model.forward_features``)."""
+    if data.dim() == 3:
+        f16, _ = model.features_from_raw(data, batch_size, want_f16=True, want_cl=False)
+        return f16.cpu().numpy()
+    hp, wp = data.shape[-2] // 14, data.shape[-1] // 14
+    chunks = []
+    for i in range(0, len(data), batch_size):
+        vec = data[i : i + batch_size]
+        f = model.forward_features(vec)["x_norm_patchtokens"]
+        f = f.reshape(f.shape[0], hp, wp, -1).permute(3, 0, 1, 2).contiguous()
+        chunks.append(f.half().cpu().numpy())
+    return np.concatenate(chunks, axis=1)
+
+
+def _save_data(data: dict[str, np.ndarray], features: np.ndarray, tomo_name: str, dst_dir: Path) -> None:
+    """``data`` (gzip), every other source leaf under ``labels/`` (gzip), ``dino_features`` uncompressed (l.119-153)."""
+    dst_dir.mkdir(parents=True, exist_ok=True)
+    with io.FileWriter(dst_dir / tomo_name) as fh:
+        for key, arr in data.items():
+            if key == "dino_features":
+                continue  # stale features of the source are dropped
+            if key == "data":
+                fh.create_dataset("data", arr, compression="gzip")
+            else:
+                fh.create_dataset(f"labels/{key}", arr, compression="gzip")
+        fh.create_dataset("dino_features", features)
+
+
+def _list_records(tomo_dir: Path, csv_file: Path) -> list[str]:
+    if csv_file.exists():
+        with open(csv_file, newline="") as f:
+            return [row["tomo_name"] for row in csv.DictReader(f)]
+    return sorted(f.name for f in tomo_dir.glob("*") if f.suffix in tomogram_exts)
+
+
+def _process_sample(src_dir: Path, dst_dir: Path, csv_dir: Path, model, sample: str, datamodule, batch_size: int,
+                    image_dir, use_sam: bool = False) -> list[str]:
+    tomo_dir, result_dir = src_dir / sample, dst_dir / sample
+    records = _list_records(tomo_dir, csv_dir / f"{sample}.csv")
+    rank, _, world = world_info()
+    mine = [records[i] for i in shard_records(records, rank, world)]
+    dataset = instantiate(datamodule.dataset, data_root=tomo_dir, use_sam=use_sam)(records=mine)
+    done = []
+    for i in range(len(dataset)):  # DataLoader(batch_size=None, num_workers=0) of the reference == plain iteration
+        x = dataset[i]
+        features = _dino_features(x, model, batch_size)
+        data = io.read_all_flat(tomo_dir / mine[i])
+        _save_data(data, features, mine[i], result_dir)
+        done.append(mine[i])
+        logging.info("[rank %d] %s/%s -> dino_features %s", rank, sample, mine[i], features.shape)
+    if image_dir is not None:
+        logging.warning("export_features=True: PCA colour maps are plotting (out of scope of this build) -- skipped")
+    return done
+
+
+def run_trainer(cfg) -> None:
+    paths = cfg.paths
+    data_dir, exp_dir = Path(paths.data_dir), Path(paths.exp_dir)
+    src_dir = data_dir / paths.feature_name  # sic: the reference reads from feature_name ...
+    dst_dir = data_dir / paths.tomo_name     # ... and writes to tomo_name (run/dino_features.py:316-317)
+    csv_dir = data_dir / paths.csv_name
+    image_dir = exp_dir / "dino_images"
+    sample = cfg.sample
+    sample_names = [getattr(sample, "name", sample)] if sample is not None else [s for s in samples if (src_dir / s).exists()]
+    if cfg.use_sam:
+        raise NotImplementedError("use_sam=True (SAM2 Hiera-L features, BASELINE configs[4]) is a later row of SURVEY s.8f")
+    enc = cfg.get("encoder", {}) or {}
+    _, local_rank, _ = world_info()
+    device = enc.get("device", "cuda:0")
+    if world_info()[2] > 1:
+        device = f"cuda:{local_rank}"
+    model = load_encoder(enc.get("name", "dinov2_vitg14_reg"), model_dir=cfg.model_dir, checkpoint=enc.get("checkpoint"),
+                         synthetic_seed=enc.get("synthetic_seed"), device=device).cuda().eval()
+    for sample_name in sample_names:
+        _process_sample(src_dir, dst_dir, csv_dir, model, sample_name, cfg.datamodule, cfg.batch_size,
+                        image_dir if cfg.export_features else None, cfg.use_sam)

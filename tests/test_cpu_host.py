@@ -1,0 +1,164 @@
+"""CPU suite, part 4: host-side mirror of the reference interface -- config composition / validation, the on-disk
+contract of ``_save_data``, dataset loading, tomogram sharding incl. a world_size-2 gloo run."""
+
+import logging
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_compose_defaults_and_overrides():
+    from cryovit_amd.config import compose, missing_keys
+
+    cfg = compose("dino_features", ["paths.model_dir=/m", "paths.data_dir=/d", "paths.exp_dir=/e", "sample=Q109", "batch_size=64"])
+    assert cfg.batch_size == 64 and cfg.sample == "Q109" and cfg.use_sam is False and cfg.export_features is False
+    assert cfg.model_dir == "/m/DINOv2" and cfg.paths.results_dir == "/e"  # ${paths.*} interpolation
+    assert cfg.paths.tomo_name == "tomograms" and cfg.paths.feature_name == "dino_features" and cfg.paths.csv_name == "csv"
+    assert cfg.datamodule.dataset._target_ == "cryovit_amd.datasets.VITDataset" and cfg.datamodule.dataset._partial_ is True
+    assert cfg.datamodule.dataset.data_root == "/d/tomograms"
+    # dino.yaml overrides the dataloader defaults: no collation, no workers (reference configs/datamodule/dino.yaml)
+    assert cfg.datamodule.dataloader.batch_size is None and cfg.datamodule.dataloader.num_workers == 0
+    assert missing_keys(cfg) == []
+
+
+def test_missing_keys_exit_1(caplog):
+    from cryovit_amd.training import dino_features
+
+    with caplog.at_level(logging.ERROR), pytest.raises(SystemExit) as e:
+        dino_features.main(["sample=Q109"])
+    assert e.value.code == 1
+    assert "paths.data_dir" in caplog.text
+
+
+def test_runtime_errors_are_logged_not_raised(tmp_path, caplog, monkeypatch):
+    """training/dino_features.py:33-37 of the reference: any exception is logged and the process returns normally."""
+    from cryovit_amd.run import dino_features as run_mod
+    from cryovit_amd.training import dino_features
+
+    def boom(cfg):
+        raise RuntimeError("no GPU here")
+
+    monkeypatch.setattr(run_mod, "run_trainer", boom)
+    with caplog.at_level(logging.ERROR):
+        dino_features.main([f"paths.model_dir={tmp_path}", f"paths.data_dir={tmp_path}", f"paths.exp_dir={tmp_path}"])
+    assert "RuntimeError: no GPU here" in caplog.text
+
+
+def test_instantiate_partial_dataset(tmp_path):
+    from cryovit_amd import io
+    from cryovit_amd.config import compose, instantiate
+
+    vol = np.random.default_rng(0).integers(0, 256, size=(5, 20, 24), dtype=np.uint8)
+    (tmp_path / "tomograms" / "Q109").mkdir(parents=True)
+    with io.FileWriter(tmp_path / "tomograms" / "Q109" / "t0.hdf") as f:
+        f.create_dataset("data", vol, compression="gzip")
+    cfg = compose("dino_features", [f"paths.model_dir={tmp_path}", f"paths.data_dir={tmp_path}", f"paths.exp_dir={tmp_path}"])
+    ds = instantiate(cfg.datamodule.dataset, data_root=tmp_path / "tomograms" / "Q109", use_sam=False)(records=["t0.hdf"])
+    x = ds[0]
+    assert x.dtype == torch.uint8 and tuple(x.shape) == (5, 20, 24) and np.array_equal(x.numpy(), vol)
+    with pytest.raises(IndexError):
+        ds[1]
+    # float volumes come back as float32, unscaled (vit_dataset.py:86-88 only rescales uint8)
+    with io.FileWriter(tmp_path / "tomograms" / "Q109" / "t1.hdf") as f:
+        f.create_dataset("data", (vol / 255.0).astype(np.float64))
+    ds = instantiate(cfg.datamodule.dataset, data_root=tmp_path / "tomograms" / "Q109", use_sam=False)(records=["t1.hdf"])
+    assert ds[0].dtype == torch.float32
+
+
+def test_save_data_layout(tmp_path):
+    """App. C: ``data`` gzip, every other source leaf under ``labels/`` gzip, ``dino_features`` contiguous float16;
+    stale source features are dropped."""
+    from cryovit_amd import io
+    from cryovit_amd.io.hdf5 import H5Reader
+    from cryovit_amd.run.dino_features import _save_data
+
+    rng = np.random.default_rng(1)
+    src = {"data": rng.integers(0, 256, size=(6, 32, 32), dtype=np.uint8), "mito": rng.integers(-1, 2, size=(6, 32, 32)).astype(np.int8),
+           "dino_features": np.zeros((4, 6, 2, 2), np.float16)}
+    feats = rng.standard_normal((8, 6, 2, 2)).astype(np.float16)
+    _save_data(src, feats, "t.hdf", tmp_path / "out" / "Q109")
+    p = tmp_path / "out" / "Q109" / "t.hdf"
+    flat = io.read_all_flat(p)
+    assert sorted(flat) == ["data", "dino_features", "mito"]
+    assert np.array_equal(flat["data"], src["data"]) and np.array_equal(flat["mito"], src["mito"])
+    assert flat["dino_features"].dtype == np.float16 and np.array_equal(flat["dino_features"], feats)
+    if not io.HAVE_H5PY:
+        with H5Reader(p) as f:
+            assert f["data"]._layout[0] == "chunked" and f["labels/mito"]._layout[0] == "chunked"
+            assert f["dino_features"]._layout[0] == "contiguous" and f["dino_features"]._filters == []
+
+
+def test_collate_fn_layout():
+    from cryovit_amd.datasets import collate_fn
+    from cryovit_amd.types import TomogramData
+
+    t = TomogramData("Q109", "a.hdf", torch.zeros(16, 5, 2, 3, dtype=torch.float16), torch.zeros(5, 32, 48, dtype=torch.int8))
+    u = TomogramData("Q109", "b.hdf", torch.zeros(16, 3, 2, 3, dtype=torch.float16), torch.zeros(3, 32, 48, dtype=torch.int8))
+    b = collate_fn([t, u])
+    assert tuple(b.tomo_batch.shape) == (2, 5, 16, 2, 3) and b.tomo_batch.dtype == torch.float32
+    assert tuple(b.labels.shape) == (2, 5, 32, 48) and torch.all(b.labels[1, 3:] == -1)  # padded depth is "ignore"
+    assert b.min_slices == 3 and b.metadata["tomo_names"] == ["a.hdf", "b.hdf"]
+
+
+def test_cryovit_state_dict_is_reference_compatible():
+    from cryovit_amd.models import CryoVIT
+    from oracle import head as oh
+
+    ref = oh.CryoVITHead()
+    mine = CryoVIT()
+    assert [(k, tuple(v.shape)) for k, v in ref.state_dict().items()] == [(k, tuple(v.shape)) for k, v in mine.state_dict().items()]
+    mine.load_state_dict(ref.state_dict())  # strict
+
+
+def test_shard_records_partition():
+    from cryovit_amd.run.sharding import shard_records
+
+    recs = [f"t{i}" for i in range(11)]
+    for world in (1, 2, 3, 8):
+        parts = [shard_records(recs, r, world) for r in range(world)]
+        assert sorted(i for p in parts for i in p) == list(range(11))
+    w = [5, 1, 1, 1, 9, 2, 2, 8, 1, 1, 1]
+    parts = [shard_records(recs, r, 2, w) for r in range(2)]
+    assert sorted(i for p in parts for i in p) == list(range(11))
+    loads = [sum(w[i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 1  # greedy balance
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+from cryovit_amd.run.sharding import gather_rows, shard_records, world_info
+rank, local, world = world_info()
+dist.init_process_group("gloo")
+recs = [f"t{i}.hdf" for i in range(7)]
+mine = shard_records(recs, rank, world)
+rows = gather_rows([(recs[i], rank, float(i) / 10) for i in mine], world)
+if rank == 0:
+    assert sorted(r[0] for r in rows) == sorted(recs), rows
+    assert {r[1] for r in rows} == {0, 1}
+    print("GATHER_OK", len(rows))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    """The N>1 path: two processes (gloo), disjoint shards, rows gathered on rank 0 -- no data-path collective."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script), str(ROOT)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "GATHER_OK 7" in r.stdout
