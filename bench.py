@@ -234,7 +234,7 @@ def main() -> None:
             "tflops_end_to_end": flops_tomo * world * args.steps / elapsed / 1e12,
             "frac_of_mfma_peak_end_to_end": flops_tomo * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS,
             "dice": 2 * i / (sy + sp + 1e-3), "pred_fg_fraction": fg,
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_nreg<128,128,2,EpiSwiGLU> (w12 GEMM + SiLU gate)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "k_gemm256_nreg<EpiSwiGLU,5> (w12 GEMM 1536->8192 + fused SiLU gate)", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "launches_timed": n_launch, "avg_launch_ms": k_ms, "flops_per_launch": k_flops},
         }
