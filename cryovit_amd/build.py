@@ -22,6 +22,9 @@ LIB = PKG / "libcryovit_hip.so"
 BUILD_DIR = PKG / "build"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# per-file extras.  attention.hip: keep the MFMA accumulators in VGPRs -- its softmax does VALU math on them every tile;
+# with the default AGPR form hipcc emitted 159 v_accvgpr_read/write per 64-key tile (tools/bench_attn.py: 536 -> see DESIGN.md)
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _sources() -> list[Path]:
@@ -34,7 +37,7 @@ def _fingerprint() -> str:
         if f.is_file():
             h.update(f.name.encode())
             h.update(f.read_bytes())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -55,7 +58,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src: Path) -> Path:
         obj = BUILD_DIR / (src.stem + ".o")
-        cmd = [hipcc, *FLAGS, "-I", str(INCLUDE), "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src.name, []), "-I", str(INCLUDE), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

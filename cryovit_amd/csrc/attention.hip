@@ -21,20 +21,39 @@ constexpr int ATT_TILE_BYTES = 64 * 128;  // 64 rows x 64 bf16
 
 __device__ __forceinline__ int pi_row(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
+// VARIANT: 0 = default (the O rescale is skipped when no row maximum of the wave moved), 1 = always rescale,
+//          10-13 = timing-only ablations (10: exp2 replaced by a multiply, 11: K/V tile 0 reused, no DMA / wait / barrier,
+//          12: DMA issued but no wait / barrier, 13: wait + barrier but no DMA)
+//          3 = THREE K/V^T buffers: tile j+2 is issued in iteration j and waited for with a counted vmcnt(4)
+template <int VARIANT>
 __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __restrict__ qk, long ldqk,
                                                            const uint16_t* __restrict__ vt, uint16_t* __restrict__ out,
-                                                           long ldo, int heads, int ntok, int ntp, int kp, int C) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * ATT_TILE_BYTES];  // [buf][K | V^T]
+                                                           long ldo, int heads, int ntok, int ntp, int kp, int C, int nqb,
+                                                           int xcd_remap) {
+    constexpr int NBUF = VARIANT == 3 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * ATT_TILE_BYTES];  // [buf][K | V^T]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slice = blockIdx.z, head = blockIdx.y;
+    // XCD-aware block order: blocks b and b+8 share an XCD (private L2).  All nqb query blocks of one (slice, head) --
+    // which stream the SAME K / V^T -- are placed on one XCD, back to back in its dispatch sequence, so a K/V tile is an
+    // L2 miss once and an L2 hit for the other query blocks.  (Placement only changes speed, never results.)
+    int qb, pair;
+    if (xcd_remap) {
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+        pair = (w / nqb) * 8 + xcd;
+        qb = w % nqb;
+    } else {
+        pair = blockIdx.x / nqb;
+        qb = blockIdx.x % nqb;
+    }
+    const int slice = pair / heads, head = pair - slice * heads;
     const long row0 = (long)slice * ntp;
     const uint16_t* Qp = qk + row0 * ldqk + head * 64;
     const uint16_t* Kp = Qp + C;
     const uint16_t* Vp = vt + ((long)(slice * heads + head) * 64) * kp;
 
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = qb * 128 + wave * 32;
     const int qrow = min(q0 + r, ntp - 1);  // rows past the slice are clamped for loads, never stored
 
     // Q fragments: B operand of S^T = K Q^T.  lane (r,h) holds Q[q0+r][16*ks + 8*h + j]
@@ -73,12 +92,25 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     const float LOG2E = 1.4426950408889634f;
 
     const int nkv = (ntok + KV_TILE - 1) / KV_TILE;
+    constexpr bool SKIP_RESCALE = VARIANT != 1, ABL_NOEXP = VARIANT == 10;
+    constexpr bool ABL_NOSYNC = VARIANT == 11 || VARIANT == 12, ABL_NODMA = VARIANT == 11 || VARIANT == 13;
     issue(0, 0);
+    if (NBUF == 3 && nkv > 1) issue(1, 1);
+    int buf = 0;  // buffer of tile j
     for (int j = 0; j < nkv; ++j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile j landed; every wave is done with tile j-1
-        if (j + 1 < nkv) issue(j + 1, (j + 1) & 1);
-        const char* kt = smem + (j & 1) * 2 * ATT_TILE_BYTES;
+        if (!ABL_NOSYNC || j == 0) {
+            // tile j landed (with three buffers tile j+1 may stay in flight); every wave is done with tile j-1
+            if (NBUF == 3 && j + 1 < nkv) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (NBUF == 3) {
+            if (j + 2 < nkv) issue(j + 2, buf == 0 ? 2 : buf - 1);  // (j+2) % 3 == (buf + 2) % 3
+        } else if (!ABL_NODMA && j + 1 < nkv) {
+            issue(ABL_NOSYNC ? 0 : j + 1, ABL_NOSYNC ? 1 : (buf ^ 1));
+        }
+        const char* kt = smem + (ABL_NOSYNC || ABL_NODMA ? 0 : buf) * 2 * ATT_TILE_BYTES;
+        buf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
         const char* vtile = kt + ATT_TILE_BYTES;
 
         // ---- S^T[t] = K_t Q^T : rows = keys (registers), col = query (lane) ----
@@ -121,13 +153,16 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[t][i], LOG2E, -mb));
+                const float p = ABL_NOEXP ? fmaf(s[t][i], LOG2E, -mb) * 0.001f : __builtin_amdgcn_exp2f(fmaf(s[t][i], LOG2E, -mb));
                 s[t][i] = p;
                 psum += p;
             }
         l_run = fmaf(l_run, alpha, psum);
+        // alpha == 1 exactly when the row maximum did not move: skip the 32-register rescale unless some lane needs it
+        if (!SKIP_RESCALE || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        }
 
         // ---- O^T[dt] += V^T[dt] P^T : accumulator registers 8s..8s+7 of S^T[t] are k-step s of the B operand ----
 #pragma unroll
@@ -166,14 +201,30 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
 
 using namespace cvx;
 
+int g_attn_variant = 0;     // cvx_set_option("attn_variant")
+int g_attn_xcd_remap = 1;   // cvx_set_option("attn_xcd_remap")
+
 extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
                                   int ntok, int ntp, int kp, hipStream_t st) {
     if (slices <= 0) return 0;
     if (ntp % 8 || kp % 64 || kp < ntok || ntp < ntok || ldqk % 8 || ldo % 4)
         return cvx_fail("attention: need ntp%8==0, kp%64==0, kp>=ntok, ntp>=ntok, ldqk%8==0");
-    if (heads > 65535 || slices > 65535) return cvx_fail("attention: heads/slices exceed grid limits");
-    dim3 grid((ntok + 127) / 128, heads, slices);
-    hipLaunchKernelGGL(k_attention, grid, dim3(ATT_THREADS), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt,
-                       (uint16_t*)out, ldo, heads, ntok, ntp, kp, heads * 64);
+    const int nqb = (ntok + 127) / 128;
+    const long nblk = (long)nqb * heads * slices;
+    if (nblk > 0x7fffffff) return cvx_fail("attention: grid too large");
+    const int xcd_remap = ((long)heads * slices) % 8 == 0 && g_attn_xcd_remap;
+    dim3 grid((unsigned)nblk);
+    void (*k)(const uint16_t*, long, const uint16_t*, uint16_t*, long, int, int, int, int, int, int, int);
+    switch (g_attn_variant) {
+        case 1: k = k_attention<1>; break;
+        case 3: k = k_attention<3>; break;
+        case 10: k = k_attention<10>; break;
+        case 11: k = k_attention<11>; break;
+        case 12: k = k_attention<12>; break;
+        case 13: k = k_attention<13>; break;
+        default: k = k_attention<0>; break;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(ATT_THREADS), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo, heads,
+                       ntok, ntp, kp, heads * 64, nqb, xcd_remap);
     return cvx_check_launch();
 }

@@ -99,20 +99,37 @@ struct EpiResid {
         load_vec<NV>(c.bias, bias + n0);
         load_vec<NV>(c.gamma, gamma + n0);
     }
+    // the residual values are PRE-LOADED for a batch of output columns before any of them is stored: issued one after
+    // the other, each load -> add -> store round trip exposed a full HBM latency (32 per lane per tile: the epilogue
+    // took as long as the whole K loop of the proj GEMM -- tools/stamp_gemm_coarse.py)
+    static constexpr bool HAS_PRELOAD = true;
+    template <int NV> struct Pre { float4 x[NV / 4]; };
     template <int NV>
-    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+    __device__ __forceinline__ void preload(Pre<NV>& p, long n0, long m) const {
+        const long mm = m < m_valid ? m : 0;
+#pragma unroll
+        for (int h = 0; h < NV / 4; ++h) p.x[h] = *(const float4*)(x + mm * ldx + (n0 + h * 4 < n_valid ? n0 + h * 4 : 0));
+    }
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, const Pre<NV>& p, long n0, long m, const float* acc) const {
         if (m >= m_valid) return;
 #pragma unroll
         for (int h = 0; h < NV / 4; ++h) {
             const long n = n0 + h * 4;
             if (n >= n_valid) continue;
-            float4 xv = *(float4*)(x + m * ldx + n);
+            float4 xv = p.x[h];
             xv.x += c.gamma[h * 4 + 0] * (acc[h * 4 + 0] + c.bias[h * 4 + 0]);
             xv.y += c.gamma[h * 4 + 1] * (acc[h * 4 + 1] + c.bias[h * 4 + 1]);
             xv.z += c.gamma[h * 4 + 2] * (acc[h * 4 + 2] + c.bias[h * 4 + 2]);
             xv.w += c.gamma[h * 4 + 3] * (acc[h * 4 + 3] + c.bias[h * 4 + 3]);
             *(float4*)(x + m * ldx + n) = xv;
         }
+    }
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+        Pre<NV> p;
+        preload<NV>(p, n0, m);
+        store<NV>(c, p, n0, m, acc);
     }
 };
 
@@ -246,35 +263,39 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_conv3_nreg(const uint16_t* in,
 // 256x256 phase-pipelined tile (gemm256.h): NREG (R = weights) and MREG (R = activations) orientations
 template <class Epi, int VARIANT>
 __global__ __launch_bounds__(G256_THREADS) void k_gemm256_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
-                                                                int tiles_n, int tiles_m, Epi epi) {
+                                                                int tiles_n, int tiles_m, Epi epi, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    stagger_first_round(stagger);
     int tr, tl;
     tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
     gemm256_body<VARIANT>(Wt, ldw, A, lda, nk, (long)tr * 256, (long)tl * 256, epi, smem);
 }
 template <class Epi, int VARIANT>
 __global__ __launch_bounds__(G256_THREADS) void k_gemm256_mreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
-                                                                int tiles_n, int tiles_m, Epi epi) {
+                                                                int tiles_n, int tiles_m, Epi epi, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    stagger_first_round(stagger);
     int tr, tl;
     tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tr, tl);
     gemm256_body<VARIANT>(A, lda, Wt, ldw, nk, (long)tr * 256, (long)tl * 256, epi, smem);
 }
 
 // tuning switches (cvx_set_option): A/B the tile kernels and pipeline schedules inside ONE process
-static int g_use_gemm256 = 1, g_gemm256_variant = 5;
+static int g_use_gemm256 = 1, g_gemm256_variant = 5, g_gemm_stagger = 0;  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
+template <class Epi> static constexpr int epilogue_cycles() { return 12000; }       // bf16 store epilogues (stamped)
+template <> constexpr int epilogue_cycles<EpiResid>() { return 40000; }              // fp32 read-modify-write
 
-template <class Epi, bool MREG>
+template <class Epi, bool MREG, int VARIANT>
 __global__ __launch_bounds__(G4W_THREADS) void k_gemm4w(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nks,
                                                          int tiles_n, int tiles_m, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tr, tl;
     if constexpr (MREG) {
         tile_coords(blockIdx.x, gridDim.x, tiles_m, tiles_n, tr, tl);
-        gemm4w_body<0>(A, lda, Wt, ldw, nks, (long)tr * 256, (long)tl * 256, epi, smem);
+        gemm4w_body<VARIANT>(A, lda, Wt, ldw, nks, (long)tr * 256, (long)tl * 256, epi, smem);
     } else {
         tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
-        gemm4w_body<0>(Wt, ldw, A, lda, nks, (long)tr * 256, (long)tl * 256, epi, smem);
+        gemm4w_body<VARIANT>(Wt, ldw, A, lda, nks, (long)tr * 256, (long)tl * 256, epi, smem);
     }
 }
 
@@ -287,14 +308,14 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
                       hipStream_t st) {
     const int tiles_n = (int)(Npad / 256), tiles_m = (int)((M + 255) / 256);
     if (g_use_gemm256 == 2) {  // one-wave-per-SIMD tile (gemm4w.h)
-        auto k4 = k_gemm4w<Epi, MREG>;
+        auto k4 = g_gemm256_variant == 1 ? k_gemm4w<Epi, MREG, 1> : g_gemm256_variant == 2 ? k_gemm4w<Epi, MREG, 2> : k_gemm4w<Epi, MREG, 0>;
         CVX_HIP(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, G4W_LDS_BYTES));
         hipLaunchKernelGGL(k4, dim3(tiles_n * tiles_m), dim3(G4W_THREADS), G4W_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / G4W_KS),
                            tiles_n, tiles_m, epi);
         return cvx_check_launch();
     }
     const int variant = g_gemm256_variant;
-    void (*k)(const uint16_t*, long, const uint16_t*, long, int, int, int, Epi);
+    void (*k)(const uint16_t*, long, const uint16_t*, long, int, int, int, Epi, int);
     if constexpr (MREG) {
         k = k_gemm256_mreg<Epi, 0>;
     } else {
@@ -303,6 +324,7 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             case 5: k = k_gemm256_nreg<Epi, 5>; break;
             case 6: k = k_gemm256_nreg<Epi, 6>; break;
             case 20: k = k_gemm256_nreg<Epi, 20>; break;
+            case 21: k = k_gemm256_nreg<Epi, 21>; break;
             case 10: k = k_gemm256_nreg<Epi, 10>; break;
             case 11: k = k_gemm256_nreg<Epi, 11>; break;
             case 12: k = k_gemm256_nreg<Epi, 12>; break;
@@ -310,8 +332,11 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
         }
     }
     CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS_BYTES));
-    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(G256_THREADS), G256_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / BK),
-                       tiles_n, tiles_m, epi);
+    // quarter of one tile's duration (~2800 cycles per K tile + epilogue), only when the launch has several rounds
+    const long nk = Kpad / BK;
+    const int stagger = (g_gemm_stagger && (long)tiles_n * tiles_m > 512) ? (int)((nk * 2800 + epilogue_cycles<Epi>()) / 4) : 0;
+    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(G256_THREADS), G256_LDS_BYTES, st, A, lda, Wt, ldw, (int)nk, tiles_n, tiles_m,
+                       epi, stagger);
     return cvx_check_launch();
 }
 
@@ -354,6 +379,8 @@ static int launch_conv3(const cvx_conv3d_desc& d, const Epi& epi, hipStream_t st
 
 using namespace cvx;
 
+extern int g_attn_variant, g_attn_xcd_remap;  // attention.hip
+
 extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
     CVX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvx::g_gemm256_dbg), sizeof(unsigned long long) * 32));
     return 0;
@@ -363,6 +390,9 @@ extern "C" int cvx_set_option(const char* name, int value) {
     if (!name) return cvx_fail("set_option: null name");
     if (!strcmp(name, "use_gemm256")) g_use_gemm256 = value;
     else if (!strcmp(name, "gemm256_variant")) g_gemm256_variant = value;
+    else if (!strcmp(name, "gemm_stagger")) g_gemm_stagger = value;
+    else if (!strcmp(name, "attn_variant")) g_attn_variant = value;
+    else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value;
     else if (!strcmp(name, "tile_group_l")) {
         if (value < 1) return cvx_fail("set_option: tile_group_l must be >= 1");
         CVX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cvx::g_tile_group_l), &value, sizeof(int)));

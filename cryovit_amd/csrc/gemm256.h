@@ -34,6 +34,9 @@ constexpr int G256_THREADS = 512;
 constexpr int G256_HALF_BYTES = 128 * 128;            // 128 rows x 64 bf16
 constexpr int G256_LDS_BYTES = 8 * G256_HALF_BYTES;   // ring of 8 half-tiles
 
+template <class E, class = void> struct epi_has_preload : std::false_type {};
+template <class E> struct epi_has_preload<E, std::enable_if_t<E::HAS_PRELOAD>> : std::true_type {};
+
 // diagnostic build only (VARIANT 20): per-wave cycle sums of the four parts of a phase, block 0 -> g_gemm256_dbg
 __device__ unsigned long long g_gemm256_dbg[8 * 4];
 __device__ __forceinline__ unsigned long long stamp() {
@@ -52,6 +55,19 @@ __device__ __forceinline__ void wait_halftiles(int pending) {
         case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+}
+
+// De-synchronise the first round of workgroups: all CUs start together and every tile takes the same time, so without
+// this the whole chip alternates between a compute phase (HBM idle) and an epilogue phase in which 256 workgroups hit HBM
+// at once (a 512-KB fp32 read-modify-write per tile took as long as the K loop of the proj GEMM).  Workgroups of the
+// first round sleep group * quarter-tile; the hardware dispatcher keeps the offsets for the rest of the launch.
+__device__ __forceinline__ void stagger_first_round(int stagger_cycles) {
+    if (stagger_cycles <= 0 || blockIdx.x >= 256) return;
+    const int group = (blockIdx.x >> 3) & 3;  // blocks b, b+8 share an XCD: spread the groups inside every XCD
+    if (group == 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long want = (unsigned long long)group * (unsigned)stagger_cycles;
+    while (__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(32);
 }
 
 template <int VARIANT, class Epi>
@@ -109,6 +125,9 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 
     [[maybe_unused]] unsigned long long dbg_load = 0, dbg_lbar = 0, dbg_mma = 0, dbg_mbar = 0;
     constexpr bool STAMP = VARIANT == 20;
+    constexpr bool COARSE = VARIANT == 21;
+    [[maybe_unused]] unsigned long long c0 = 0, c1 = 0, c2 = 0;
+    if constexpr (COARSE) c0 = stamp();
     if constexpr (VARIANT == 6) {
     // ---- variant 6: TWO phases of 32 MFMAs per K tile (half the barriers): A = (R, L-lo), B = (R, L-hi); the DMA runs
     //      exactly one K tile ahead (R halves issued in phase A, L halves in phase B) ----
@@ -201,11 +220,12 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     if (total > 5) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wl == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 run one barrier behind
+    if constexpr (COARSE) c1 = stamp();
 
     // one K tile.  STEADY: all four DMA issues exist -> unconditional issue + exact counted waits (no branches).
     // ISSUE_IN_MMA: the DMA is issued from the MFMA segment (in the issue gaps of the wave's own MFMAs) instead of the
     // load segment, which is the critical one (it competes for issue slots with the partner wave's MFMA stream).
-    constexpr bool ISSUE_IN_MMA = (VARIANT == 5);
+    constexpr bool ISSUE_IN_MMA = (VARIANT == 5 || VARIANT == 21);
     auto ktile = [&](int t, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         const char* st = smem + (t & 1) * 4 * G256_HALF_BYTES;
@@ -357,6 +377,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     if (wl == 0) __builtin_amdgcn_s_barrier();  // pairs with the stagger barrier of waves 4-7
 
     }
+    if constexpr (COARSE) c2 = stamp();
     if constexpr (STAMP) {
         if (blockIdx.x == 0 && lane == 0) {
             g_gemm256_dbg[wave * 4 + 0] = dbg_load; g_gemm256_dbg[wave * 4 + 1] = dbg_lbar;
@@ -368,6 +389,49 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     const long rbase = r0 + wr * 64 + gq * 16;
     typename Epi::template Ctx<16> ctx;
     epi.template prep<16>(ctx, rbase);
+    if constexpr (epi_has_preload<Epi>::value) {
+        // fp32 read-modify-write epilogue (residual stream), staged through LDS.  In accumulator layout a wave
+        // instruction touches 16 rows x four 16-B pieces: every load/store moved 1 KiB but opened 32 cache lines, and
+        // the 512-KB RMW of a tile took as long as the whole K loop of the proj GEMM (tools/stamp_gemm_coarse.py).
+        // Each wave transposes its 64 x 128 tile through a private 32-row x 272-B LDS buffer (the DMA ring is idle
+        // now; no barrier: a wave only reads what it wrote and LDS ops of one wave complete in order) so that one
+        // instruction covers 4 rows x 256 contiguous bytes.
+        constexpr int PITCH = 68;  // floats per staged row (64 + 4 pad)
+        float* stg = (float*)smem + wave * 32 * PITCH;
+        const int mrow = lane >> 4, ncol = (lane & 15) * 4;
+        const long nglob = r0 + wr * 64 + ncol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float4 d;
+                    d.x = ctx.gamma[f * 4 + 0] * (acc[f][2 * q + bb][0] + ctx.bias[f * 4 + 0]);
+                    d.y = ctx.gamma[f * 4 + 1] * (acc[f][2 * q + bb][1] + ctx.bias[f * 4 + 1]);
+                    d.z = ctx.gamma[f * 4 + 2] * (acc[f][2 * q + bb][2] + ctx.bias[f * 4 + 2]);
+                    d.w = ctx.gamma[f * 4 + 3] * (acc[f][2 * q + bb][3] + ctx.bias[f * 4 + 3]);
+                    *(float4*)(stg + (16 * bb + (lane & 15)) * PITCH + 16 * gq + 4 * f) = d;
+                }
+            float4 xv[8];
+            const long mbase = l0 + wl * 128 + 32 * q + mrow;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long m = mbase + 4 * i;
+                xv[i] = (m < epi.m_valid && nglob < epi.n_valid) ? *(const float4*)(epi.x + m * epi.ldx + nglob) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long m = mbase + 4 * i;
+                const float4 d = *(const float4*)(stg + (4 * i + mrow) * PITCH + ncol);
+                if (m < epi.m_valid && nglob < epi.n_valid) {
+                    float4 o;
+                    o.x = xv[i].x + d.x; o.y = xv[i].y + d.y; o.z = xv[i].z + d.z; o.w = xv[i].w + d.w;
+                    *(float4*)(epi.x + m * epi.ldx + nglob) = o;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const long l = l0 + wl * 128 + b * 16 + (lane & 15);
@@ -377,6 +441,15 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][b][e];
         epi.template store<16>(ctx, rbase, l, v);
+    }
+    }
+    if constexpr (COARSE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long c3 = stamp();
+        if (blockIdx.x == 8 * 20 && lane == 0) {  // a block in the middle of an XCD's first round
+            g_gemm256_dbg[wave * 4 + 0] = c1 - c0; g_gemm256_dbg[wave * 4 + 1] = c2 - c1;
+            g_gemm256_dbg[wave * 4 + 2] = c3 - c2; g_gemm256_dbg[wave * 4 + 3] = c3 - c0;
+        }
     }
 }
 

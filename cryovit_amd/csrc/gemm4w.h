@@ -91,14 +91,14 @@ __device__ __forceinline__ void gemm4w_body(const uint16_t* __restrict__ Rmat, l
         // sub-stage j+1 (8 pieces per wave) must have landed; j+2, j+3 may stay in flight
         // (lgkmcnt(0): this wave's ds_reads of sub-stage j, issued a whole k-step ago, are complete -> its slot may be
         //  rewritten by whoever passes the barrier first)
-        if constexpr (STEADY) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        if constexpr (STEADY && VARIANT != 1) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const bool do_issue = STEADY || j + 4 < nks, do_read = STEADY || j + 1 < nks;
+        const bool do_issue = VARIANT != 1 && (STEADY || j + 4 < nks), do_read = STEADY || j + 1 < nks;
         char* dst = smem + ((j + 4) & (G4W_RING - 1)) * G4W_SUB_BYTES;
         const char* nst = smem + ((j + 1) & (G4W_RING - 1)) * G4W_SUB_BYTES;
-        const uint16_t* rs = Rb + (j + 4) * G4W_KS;
-        const uint16_t* ls = Lb + (j + 4) * G4W_KS;
+        const uint16_t* rs = Rb + (VARIANT == 2 ? 0 : (j + 4) * G4W_KS);  // VARIANT 1/2: timing-only ablations (no DMA / L2-resident DMA)
+        const uint16_t* ls = Lb + (VARIANT == 2 ? 0 : (j + 4) * G4W_KS);
         // hand interleave: per row of 8 MFMAs one LDS-DMA piece of sub-stage j+4 and two fragment reads of k-step j+1
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
