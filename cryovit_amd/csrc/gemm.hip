@@ -328,6 +328,7 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             case 10: k = k_gemm256_nreg<Epi, 10>; break;
             case 11: k = k_gemm256_nreg<Epi, 11>; break;
             case 12: k = k_gemm256_nreg<Epi, 12>; break;
+            case 13: k = k_gemm256_nreg<Epi, 13>; break;
             default: k = k_gemm256_nreg<Epi, 0>; break;
         }
     }

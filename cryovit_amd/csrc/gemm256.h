@@ -98,6 +98,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     // timing-only ablations (results are garbage): 10 = no DMA in the loop, 11 = DMA always from K tile 0 (L2-resident),
     // 12 = no fragment reads in the loop
     constexpr bool ABL_NO_DMA = VARIANT == 10, ABL_SAME_K = VARIANT == 11, ABL_NO_READ = VARIANT == 12;
+    constexpr bool ABL_NO_R_DMA = VARIANT == 13;  // only the L half-tiles are DMA'd (what a weights-bypass-LDS kernel would move)
     auto issue = [&](int q) {  // half-tile q -> ring slot q & 7
         const int kt = ABL_SAME_K ? 0 : (q >> 2), kind = q & 3;
         char* dst = smem + (q & 7) * G256_HALF_BYTES + wave * 1024;
@@ -107,6 +108,11 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
         const uint16_t* src = (isL ? Lb : Rb) + kt * BK;
         const uint32_t o0 = isL ? offL[half][0] : offR[half][0];
         const uint32_t o1 = isL ? offL[half][1] : offR[half][1];
+        if (ABL_NO_R_DMA && !isL) {  // keep the vmcnt arithmetic: two cheap L2-resident pieces instead
+            glds16(Lb + o0 % 64, dst);
+            glds16(Lb + o1 % 64, dst + G256_THREADS * 16);
+            return;
+        }
         glds16(src + o0, dst);
         glds16(src + o1, dst + G256_THREADS * 16);
     };

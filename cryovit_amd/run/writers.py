@@ -1,0 +1,66 @@
+"""Output files of the evaluation / inference flows (mirror of the formats written by
+``/root/reference/src/cryovit/models/callbacks.py``; SURVEY.md App. C, "next" row N1).
+
+  write_test_prediction  TestPredictionWriter l.15-58:  ``data`` contiguous, ``<label>`` gzip, ``<label>_preds`` fp32 gzip at
+                         <results_dir>/<sample>/<tomo_name>
+  write_prediction       PredictionWriter l.61-109:     ``data`` fp32 gzip, ``<label>_preds`` uint8 (preds >= threshold) gzip
+                         at <results_dir>/<tomo stem>.hdf
+  update_metrics_csv     CsvWriter l.112-206:           <results_dir>/<sample>[_<split>].csv, columns sample, tomo_name,
+                         <metrics...>[, split_id]; an existing row for the same tomogram is replaced
+"""
+
+from __future__ import annotations
+
+import csv
+import logging
+from pathlib import Path
+
+import numpy as np
+
+from cryovit_amd import io
+
+
+def write_test_prediction(results_dir, sample: str, tomo_name: str, label_key: str, data: np.ndarray, labels: np.ndarray,
+                          preds: np.ndarray) -> Path:
+    out = Path(results_dir) / sample / tomo_name
+    with io.FileWriter(out) as fh:
+        fh.create_dataset("data", data)
+        fh.create_dataset(label_key, labels, compression="gzip")
+        fh.create_dataset(f"{label_key}_preds", preds.astype(np.float32, copy=False), compression="gzip")
+    return out
+
+
+def write_prediction(results_dir, tomo_name: str, label_key: str, data: np.ndarray, preds: np.ndarray, threshold: float) -> Path:
+    out = (Path(results_dir) / tomo_name).with_suffix(".hdf")
+    with io.FileWriter(out) as fh:
+        fh.create_dataset("data", data.astype(np.float32), compression="gzip")
+        fh.create_dataset(f"{label_key}_preds", (preds >= threshold).astype(np.uint8), compression="gzip")
+    return out
+
+
+def update_metrics_csv(results_dir, sample: str, tomo_name: str, metrics: dict[str, float], split_id=None) -> Path:
+    results_dir = Path(results_dir)
+    results_dir.mkdir(parents=True, exist_ok=True)
+    path = results_dir / f"{sample}{'' if split_id is None else f'_{split_id}'}.csv"
+    columns = ["sample", "tomo_name", *metrics] + (["split_id"] if split_id is not None else [])
+    rows: list[dict] = []
+    if path.exists():
+        with open(path, newline="") as f:
+            rows = list(csv.DictReader(f))
+    def same(r):
+        return r.get("tomo_name") == tomo_name and r.get("sample") == sample and (split_id is None or str(r.get("split_id")) == str(split_id))
+    n_old = sum(same(r) for r in rows)
+    if n_old:
+        logging.warning("Data with sample %s, name %s, and split %s already has an entry. Replacing %d rows...", sample, tomo_name,
+                        split_id, n_old)
+        rows = [r for r in rows if not same(r)]
+    new = {"sample": sample, "tomo_name": tomo_name, **{k: repr(float(v)) for k, v in metrics.items()}}
+    if split_id is not None:
+        new["split_id"] = split_id
+    rows.append(new)
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=columns, extrasaction="ignore")
+        w.writeheader()
+        for r in rows:
+            w.writerow(r)
+    return path

@@ -162,3 +162,39 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
                         "--master-port", str(port), str(script), str(ROOT)], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "GATHER_OK 7" in r.stdout
+
+
+def test_metrics_csv_semantics(tmp_path, caplog):
+    """CsvWriter (callbacks.py:112-206): per-sample file, header sample,tomo_name,<metrics>, re-evaluated rows replaced."""
+    import csv
+
+    from cryovit_amd.run.writers import update_metrics_csv
+
+    p = update_metrics_csv(tmp_path, "Q109", "a.hdf", {"dice_metric": 0.5})
+    update_metrics_csv(tmp_path, "Q109", "b.hdf", {"dice_metric": 0.25})
+    with caplog.at_level(logging.WARNING):
+        update_metrics_csv(tmp_path, "Q109", "a.hdf", {"dice_metric": 0.75})
+    assert "already has an entry" in caplog.text
+    rows = list(csv.DictReader(open(p)))
+    assert p.name == "Q109.csv" and list(rows[0].keys()) == ["sample", "tomo_name", "dice_metric"]
+    assert {r["tomo_name"]: float(r["dice_metric"]) for r in rows} == {"a.hdf": 0.75, "b.hdf": 0.25}
+    p2 = update_metrics_csv(tmp_path, "Q109", "a.hdf", {"dice_metric": 0.1}, split_id=3)
+    assert p2.name == "Q109_3.csv" and list(csv.DictReader(open(p2)))[0]["split_id"] == "3"
+
+
+def test_prediction_file_formats(tmp_path):
+    from cryovit_amd import io
+    from cryovit_amd.run.writers import write_prediction, write_test_prediction
+
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 256, size=(4, 16, 16), dtype=np.uint8)
+    lab = rng.integers(-1, 2, size=(4, 16, 16)).astype(np.int8)
+    preds = rng.random((4, 16, 16)).astype(np.float32)
+    p = write_test_prediction(tmp_path, "Q109", "t.hdf", "mito", data, lab, preds)
+    assert p == tmp_path / "Q109" / "t.hdf" and sorted(io.list_keys(p)) == ["data", "mito", "mito_preds"]
+    assert np.array_equal(io.read_dataset(p, "mito_preds"), preds) and io.read_dataset(p, "mito_preds").dtype == np.float32
+    q = write_prediction(tmp_path / "inf", "t.mrc", "mito", data, preds, 0.5)
+    assert q.name == "t.hdf"
+    seg = io.read_dataset(q, "mito_preds")
+    assert seg.dtype == np.uint8 and np.array_equal(seg, (preds >= 0.5).astype(np.uint8))
+    assert io.read_dataset(q, "data").dtype == np.float32

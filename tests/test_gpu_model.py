@@ -170,3 +170,72 @@ def test_e2e_tiny_golden(gpu, gold):
     dice = 2 * i / (sy + sp + 1e-3)
     flips = int(((got > 0) != (ref_logit > 0)).sum())
     assert abs(dice - float(g["dice"])) <= 1e-3, (dice, float(g["dice"]), f"{flips} of {got.numel()} voxels changed side of the threshold")
+
+
+def test_vit_g_full_depth_one_slice_vs_oracle(gpu):
+    """The REAL encoder configuration (ViT-g/14-reg: dim 1536, 40 layers, 24 heads, SwiGLU 4096) end to end on two raw
+    128x128 uint8 slices against the CPU oracle with the same seeded weights: 40 layers of bf16 GEMM / attention error
+    accumulation must stay inside the stated tolerance."""
+    from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine, random_state_dict
+    from oracle import dinov2 as o
+    from oracle import features as ofe
+    from oracle import preprocess as opre
+
+    cfg = VIT_CONFIGS["dinov2_vitg14_reg"]
+    sd_dev = random_state_dict(cfg, seed=2, device=gpu)
+    eng = VitEngine(cfg, sd_dev, gpu)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    del sd_dev
+    vol = np.random.default_rng(77).integers(0, 256, size=(2, 128, 128), dtype=np.uint8)
+    ref = ofe.dino_features(opre.dino_transform(opre.load_scale(vol)), o.OracleDino(o.VITG14_REG, sd), 2)  # [1536,2,8,8] fp16
+    f16 = torch.zeros(1536, 2, 8, 8, dtype=torch.float16, device=gpu)
+    eng.features(torch.from_numpy(vol).to(gpu), feats_f16=f16, d_total=2, d0=0)
+    _check_tokens(f16.float().cpu(), torch.from_numpy(ref.astype(np.float32)))
+
+
+def test_full_size_properties(gpu):
+    """BASELINE size (128x512x512, ViT-g + full-width head): properties that need no CPU oracle.
+      * determinism: the ViT path has no atomics -> two runs give bit-identical fp16 features
+      * slice equivariance: reversing the slice order reverses the features (slices are independent in the ViT)
+      * head output range: probabilities inside [sigmoid(-5), sigmoid(5)] (the clip of cryovit.py:39)
+      * Dice sums: recomputed from the GPU's own probabilities and labels, bit-exact (integer-valued fp32 sums)"""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import HeadEngine
+    from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine, random_state_dict
+
+    cfg = VIT_CONFIGS["dinov2_vitg14_reg"]
+    vit = VitEngine(cfg, random_state_dict(cfg, seed=2, device=gpu), gpu)
+    head = HeadEngine(bench.synthetic_head_state_dict(5, gpu), gpu)
+    D, H, W = 128, 512, 512
+    vol = (torch.rand(D, H, W, generator=torch.Generator().manual_seed(100)) * 255).to(torch.uint8).to(gpu)
+    hp = wp = 32
+    f_a = torch.zeros(1536, D, hp, wp, dtype=torch.float16, device=gpu)
+    f_b = torch.zeros_like(f_a)
+    cl = torch.zeros(ops.alloc_rows(D * hp * wp), 1536, dtype=torch.bfloat16, device=gpu)
+    vit.features(vol, feats_f16=f_a, d_total=D, d0=0, feats_cl=cl)
+    vit.features(vol, feats_f16=f_b, d_total=D, d0=0)
+    assert torch.equal(f_a, f_b), "ViT path is not deterministic"
+    assert torch.isfinite(f_a.float()).all()
+    s = f_a.float()
+    assert abs(float(s.mean())) < 0.2 and 0.5 < float(s.std()) < 2.0  # LayerNorm outputs: ~zero mean, ~unit scale
+    vit.features(vol.flip(0).contiguous(), feats_f16=f_b, d_total=D, d0=0)
+    err = (f_b.flip(1).float() - f_a.float()).abs()  # same slices, different rows of the batch -> different tiles
+    assert float(err.max()) <= 5e-2 and float(err.mean()) <= 2e-3, (float(err.max()), float(err.mean()))
+    labels = bench.synthetic_labels(gpu, 4)
+    out = head.forward(cl, D, hp, wp, labels=labels, want_logits=True)
+    p, lg = out["probs"], out["logits"]
+    assert tuple(p.shape) == (D, H, W)
+    assert float(lg.min()) >= -5.0 and float(lg.max()) <= 5.0
+    assert float(p.min()) >= 0.00669 and float(p.max()) <= 0.99331
+    mask = labels > -1
+    ph = (p >= 0.5) & mask
+    lab1 = (labels == 1) & mask
+    want = torch.tensor([float((ph & lab1).sum()), float(lab1.sum()), float(ph.sum())])
+    assert torch.equal(out["dice_sums"].cpu(), want), (out["dice_sums"].cpu(), want)
+    fg = float((p >= 0.5).float().mean())
+    assert 0.05 < fg < 0.95, f"degenerate synthetic head (fg fraction {fg})"

@@ -79,3 +79,44 @@ def test_dice_metric(gpu, gold):
     assert abs(v - float(g["dice"])) < 1e-6 and abs(m.compute() - float(g["dice"])) < 1e-6
     m.reset()
     assert m.compute() == 0.0
+
+
+def test_end_to_end_runner_configs_2_and_3(gpu, tmp_path):
+    """configs[2]/[3] plumbing at small size: three synthetic tomograms -> run_segmentation twice, once from raw ``data``
+    through the ViT-g encoder (features never leave HBM) and once from the ``dino_features`` written by the feature
+    stage; both must agree with each other, with the CSV, and with the prediction files."""
+    import csv
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    from cryovit_amd import io
+    from cryovit_amd.models import CryoVIT, load_encoder
+    from cryovit_amd.run.dino_features import _dino_features, _save_data
+    from cryovit_amd.run.segment import run_segmentation
+
+    enc = load_encoder("dinov2_vitg14_reg", synthetic_seed=2, device=gpu)
+    model = CryoVIT(device=gpu)
+    model.load_state_dict({k: v.cpu() for k, v in bench.synthetic_head_state_dict(5, gpu).items()})
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(3):
+        vol = rng.integers(0, 256, size=(6 + i, 64, 48), dtype=np.uint8)
+        lab = rng.integers(-1, 2, size=vol.shape).astype(np.int8)
+        feats = _dino_features(torch.from_numpy(vol), enc, 4)
+        assert feats.shape == (1536, vol.shape[0], 4, 3) and feats.dtype == np.float16
+        _save_data({"data": vol, "mito": lab}, feats, f"t{i}.hdf", tmp_path / "tomograms" / "Q109")
+        recs.append(("Q109", tmp_path / "tomograms" / "Q109" / f"t{i}.hdf"))
+    rows_e2e = run_segmentation(recs, model, "mito", results_dir=tmp_path / "res_e2e", encoder=enc, batch_size=4)
+    rows_feat = run_segmentation(recs, model, "mito", results_dir=tmp_path / "res_feat", save_predictions=True)
+    assert [r["tomo_name"] for r in rows_e2e] == ["t0.hdf", "t1.hdf", "t2.hdf"]
+    for a, b in zip(rows_e2e, rows_feat):
+        assert 0.0 < a["dice_metric"] < 1.0
+        assert abs(a["dice_metric"] - b["dice_metric"]) <= 2e-3  # fp16 feature file vs bf16 in-HBM hand-over
+    got = {r["tomo_name"]: float(r["dice_metric"]) for r in csv.DictReader(open(tmp_path / "res_feat" / "results" / "Q109.csv"))}
+    assert got == {r["tomo_name"]: r["dice_metric"] for r in rows_feat}
+    pred = tmp_path / "res_feat" / "predictions" / "Q109" / "t1.hdf"
+    assert sorted(io.list_keys(pred)) == ["data", "mito", "mito_preds"]
+    p = io.read_dataset(pred, "mito_preds")
+    assert p.dtype == np.float32 and p.shape == (7, 64, 48) and 0.0066 <= p.min() and p.max() <= 0.9934
