@@ -137,6 +137,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slice-batch", type=int, default=128, help="slices per ViT launch sequence (reference default 128)")
+    ap.add_argument("--streams", type=int, default=1, help="tomograms in flight per GPU, one per HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -177,11 +178,26 @@ def main() -> None:
     feats_f16 = torch.zeros(cfg.dim, D_, hp, wp, dtype=torch.float16, device=dev)  # the on-disk `dino_features` tensor
     sb = args.slice_batch
 
+    # args.streams volumes in flight, one per HIP stream (north_star: "one volume per HIP stream"): kernels of different
+    # volumes fill each other's tails and epilogue bubbles.  Every context has private workspaces; weights are shared.
+    S = max(1, args.streams)
+    ctxs = []
+    for k in range(S):
+        ctxs.append({
+            "vit": vit if k == 0 else vit.clone_for_stream(), "head": head if k == 0 else head.clone_for_stream(),
+            "stream": torch.cuda.current_stream() if k == 0 else torch.cuda.Stream(device=dev),
+            "cl": feats_cl if k == 0 else torch.zeros_like(feats_cl), "f16": feats_f16 if k == 0 else torch.zeros_like(feats_f16),
+        })
+    step_no = [0]
+
     def step():
-        for d0 in range(0, D_, sb):
-            b = min(sb, D_ - d0)
-            vit.features(vol[d0 : d0 + b], feats_f16=feats_f16, d_total=D_, d0=d0, feats_cl=feats_cl[d0 * hp * wp :])
-        return head.forward(feats_cl, D_, hp, wp, labels=labels, want_probs=True)
+        c = ctxs[step_no[0] % S]
+        step_no[0] += 1
+        with torch.cuda.stream(c["stream"]):
+            for d0 in range(0, D_, sb):
+                b = min(sb, D_ - d0)
+                c["vit"].features(vol[d0 : d0 + b], feats_f16=c["f16"], d_total=D_, d0=d0, feats_cl=c["cl"][d0 * hp * wp :])
+            return c["head"].forward(c["cl"], D_, hp, wp, labels=labels, want_probs=True)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -230,7 +246,7 @@ def main() -> None:
             "config": {"workload": "one 128x512x512 uint8 tomogram per step per GPU: fused resize + DINOv2 ViT-g/14-reg "
                                    "(40 layers, N=1029 tokens/slice) -> fp16 dino_features [1536,128,32,32] + CryoVIT head "
                                    "[1,1536,128,32,32] -> probs [128,512,512] + masked Dice; synthetic weights",
-                       "slice_batch": sb, "parallelism": f"tomogram-sharded x{world}, no collectives"},
+                       "slice_batch": sb, "streams": args.streams, "parallelism": f"tomogram-sharded x{world}, no collectives"},
             "tflops_end_to_end": flops_tomo * world * args.steps / elapsed / 1e12,
             "frac_of_mfma_peak_end_to_end": flops_tomo * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS,
             "dice": 2 * i / (sy + sp + 1e-3), "pred_fg_fraction": fg,

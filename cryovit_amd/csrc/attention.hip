@@ -197,6 +197,173 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64 query rows per wave (two 32-row groups that share every K / V^T fragment read, the LDS-DMA and the barrier of a
+// tile): half the LDS reads, DMA instructions and barriers per query row, and inside ONE wave the softmax VALU work of
+// one group can overlap the MFMAs of the other.  NW waves per workgroup (NW*64 query rows).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restrict__ qk, long ldqk, const uint16_t* __restrict__ vt,
+                                                         uint16_t* __restrict__ out, long ldo, int heads, int ntok, int ntp, int kp,
+                                                         int C, int nqb, int xcd_remap) {
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * ATT_TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int qb, pair;
+    if (xcd_remap) {
+        const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
+        pair = (w / nqb) * 8 + xcd;
+        qb = w % nqb;
+    } else {
+        pair = blockIdx.x / nqb;
+        qb = blockIdx.x % nqb;
+    }
+    const int slice = pair / heads, head = pair - slice * heads;
+    const long row0 = (long)slice * ntp;
+    const uint16_t* Qp = qk + row0 * ldqk + head * 64;
+    const uint16_t* Kp = Qp + C;
+    const uint16_t* Vp = vt + ((long)(slice * heads + head) * 64) * kp;
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = qb * NT + wave * 64;
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qrow = min(q0 + 32 * g + r, ntp - 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *(const bf16x8*)(Qp + (long)qrow * ldqk + 16 * ks + 8 * h);
+    }
+    // LDS-DMA: 512 16-B pieces per K tile and per V^T tile, NT threads
+    constexpr int NP = (512 + NT - 1) / NT;
+    int srow[NP], schunk[NP];
+#pragma unroll
+    for (int jj = 0; jj < NP; ++jj) {
+        const int c = jj * NT + tid;
+        srow[jj] = (c >> 3) & 63;
+        schunk[jj] = ((c & 7) ^ ((srow[jj] >> 1) & 7)) << 3;
+    }
+    auto issue = [&](int j, int buf) {
+        char* kt = smem + buf * 2 * ATT_TILE_BYTES;
+        char* vtile = kt + ATT_TILE_BYTES;
+        const long kv0 = (long)j * KV_TILE;
+#pragma unroll
+        for (int jj = 0; jj < NP; ++jj) {
+            if (jj * NT + wave * 64 >= 512) break;  // wave-uniform: the last pass may cover only some waves
+            glds16(Kp + (kv0 + srow[jj]) * ldqk + schunk[jj], kt + (jj * NT + wave * 64) * 16);
+            glds16(Vp + (long)srow[jj] * kp + kv0 + schunk[jj], vtile + (jj * NT + wave * 64) * 16);
+        }
+    };
+    const int krow = pi_row(r);
+    const int koff = krow * 128, ksw = (krow >> 1) & 7;
+    const int voff = r * 128, vsw = (r >> 1) & 7;
+
+    f32x16 o[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[g][0][i] = 0.f; o[g][1][i] = 0.f; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const float LOG2E = 1.4426950408889634f;
+    const int nkv = (ntok + KV_TILE - 1) / KV_TILE;
+
+    issue(0, 0);
+    for (int j = 0; j < nkv; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (j + 1 < nkv) issue(j + 1, (j + 1) & 1);
+        const char* kt = smem + (j & 1) * 2 * ATT_TILE_BYTES;
+        const char* vtile = kt + ATT_TILE_BYTES;
+
+        f32x16 s[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[g][0][i] = 0.f; s[g][1][i] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(kt + t * 4096 + koff + (((2 * ks + h) ^ ksw) << 4));
+                s[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ks], s[0][t], 0, 0, 0);
+                s[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ks], s[1][t], 0, 0, 0);
+            }
+        const int kv0 = j * KV_TILE;
+        if (kv0 + KV_TILE > ntok) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (kv0 + 32 * t + pi_row(rho) >= ntok) s[g][t][i] = -INFINITY;
+                    }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float mloc = s[g][0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, s[g][0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, s[g][1][i]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run[g], mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[g] - m_new) * LOG2E);
+            const float mb = m_new * LOG2E;
+            m_run[g] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[g][t][i], LOG2E, -mb));
+                    s[g][t][i] = p;
+                    psum += p;
+                }
+            l_run[g] = fmaf(l_run[g], alpha, psum);
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o[g][0][i] *= alpha; o[g][1][i] *= alpha; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                bf16x8 pf[2];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[g][e] = (__bf16)s[g][t][8 * sk + e];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x8 vf = *(const bf16x8*)(vtile + dt * 4096 + voff + (((4 * t + 2 * sk + h) ^ vsw) << 4));
+                    o[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0], o[0][dt], 0, 0, 0);
+                    o[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1], o[1][dt], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int q = q0 + 32 * g + r;
+        if (q < ntok) {
+            uint16_t* orow = out + (row0 + q) * ldo + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    uint2 w;
+                    w.x = pack2bf(o[g][dt][4 * gg + 0] * inv, o[g][dt][4 * gg + 1] * inv);
+                    w.y = pack2bf(o[g][dt][4 * gg + 2] * inv, o[g][dt][4 * gg + 3] * inv);
+                    *(uint2*)(orow + 32 * dt + 8 * gg + 4 * h) = w;
+                }
+        }
+    }
+}
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -209,7 +376,8 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     if (slices <= 0) return 0;
     if (ntp % 8 || kp % 64 || kp < ntok || ntp < ntok || ldqk % 8 || ldo % 4)
         return cvx_fail("attention: need ntp%8==0, kp%64==0, kp>=ntok, ntp>=ntok, ldqk%8==0");
-    const int nqb = (ntok + 127) / 128;
+    const int rows_per_block = g_attn_variant == 4 ? 192 : g_attn_variant == 5 ? 256 : 128;
+    const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;
     if (nblk > 0x7fffffff) return cvx_fail("attention: grid too large");
     const int xcd_remap = ((long)heads * slices) % 8 == 0 && g_attn_xcd_remap;
@@ -223,6 +391,12 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
         case 12: k = k_attention<12>; break;
         case 13: k = k_attention<13>; break;
         default: k = k_attention<0>; break;
+    }
+    if (g_attn_variant == 4 || g_attn_variant == 5) {
+        auto k64 = g_attn_variant == 4 ? k_attention64<3> : k_attention64<4>;
+        hipLaunchKernelGGL(k64, grid, dim3(rows_per_block), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo,
+                           heads, ntok, ntp, kp, heads * 64, nqb, xcd_remap);
+        return cvx_check_launch();
     }
     hipLaunchKernelGGL(k, grid, dim3(ATT_THREADS), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo, heads,
                        ntok, ntp, kp, heads * 64, nqb, xcd_remap);

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(G256_THREADS) void k_gemm256_nreg(const uint16_t* A
     stagger_first_round(stagger);
     int tr, tl;
     tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
-    gemm256_body<VARIANT>(Wt, ldw, A, lda, nk, (long)tr * 256, (long)tl * 256, epi, smem);
+    const int koff = VARIANT == 7 ? ((tr & 3) + (tl & 7)) % nk : 0;
+    gemm256_body<(VARIANT == 7 ? 5 : VARIANT)>(Wt, ldw, A, lda, nk, (long)tr * 256, (long)tl * 256, epi, smem, koff);
 }
 template <class Epi, int VARIANT>
 __global__ __launch_bounds__(G256_THREADS) void k_gemm256_mreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
@@ -323,6 +324,7 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             case 1: k = k_gemm256_nreg<Epi, 1>; break;
             case 5: k = k_gemm256_nreg<Epi, 5>; break;
             case 6: k = k_gemm256_nreg<Epi, 6>; break;
+            case 7: k = k_gemm256_nreg<Epi, 7>; break;
             case 20: k = k_gemm256_nreg<Epi, 20>; break;
             case 21: k = k_gemm256_nreg<Epi, 21>; break;
             case 10: k = k_gemm256_nreg<Epi, 10>; break;

@@ -72,7 +72,7 @@ __device__ __forceinline__ void stagger_first_round(int stagger_cycles) {
 
 template <int VARIANT, class Epi>
 __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, long ldr, const uint16_t* __restrict__ Lmat,
-                                             long ldl, int nk, long r0, long l0, const Epi& epi, char* smem) {
+                                             long ldl, int nk, long r0, long l0, const Epi& epi, char* smem, int koff = 0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 3, wl = wave >> 2;  // waves 0-3 / 4-7 = L half 0 / 1 = the two stagger groups
@@ -100,7 +100,11 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     constexpr bool ABL_NO_DMA = VARIANT == 10, ABL_SAME_K = VARIANT == 11, ABL_NO_READ = VARIANT == 12;
     constexpr bool ABL_NO_R_DMA = VARIANT == 13;  // only the L half-tiles are DMA'd (what a weights-bypass-LDS kernel would move)
     auto issue = [&](int q) {  // half-tile q -> ring slot q & 7
-        const int kt = ABL_SAME_K ? 0 : (q >> 2), kind = q & 3;
+        // koff rotates the K order per workgroup (variant 7): workgroups that share an operand panel then request its K
+        // slabs at different times, so the later ones find the lines IN L2 instead of queueing behind the same miss
+        int kt = ABL_SAME_K ? 0 : (q >> 2) + koff;
+        if (kt >= nk) kt -= nk;
+        const int kind = q & 3;
         char* dst = smem + (q & 7) * G256_HALF_BYTES + wave * 1024;
         // slot order inside a K tile: variants 0-5: R-lo, L-lo, R-hi, L-hi;  variant 6: R-lo, R-hi, L-lo, L-hi
         const bool isL = VARIANT == 6 ? (kind >= 2) : (kind & 1);

@@ -103,6 +103,14 @@ class HeadEngine:
         self.stats = torch.zeros(2 * 256, dtype=torch.float32, device=self.device)
         self._ws = {}
 
+    def clone_for_stream(self) -> "HeadEngine":
+        """Second launch context over the same packed weights with private activation buffers (one per HIP stream)."""
+        other = object.__new__(HeadEngine)
+        other.__dict__.update(self.__dict__)
+        other._ws = {}
+        other.stats = torch.zeros_like(self.stats)
+        return other
+
     def _buf(self, name: str, rows: int, ch: int) -> torch.Tensor:
         """bf16 [rows + slack][ch] channels-last buffer (slack rows let K-padded GEMM loads run past the end)."""
         key = (name, rows, ch)

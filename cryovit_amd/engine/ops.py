@@ -137,9 +137,10 @@ def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs
     _dev_check(x, w, logits, probs, labels, dice)
     scratch = None
     if labels is not None:
-        scratch = _dice_scratch.get(x.device)
+        key = (x.device, _stream())  # per stream: two volumes may be in flight at once
+        scratch = _dice_scratch.get(key)
         if scratch is None:
-            scratch = _dice_scratch[x.device] = torch.zeros(3 * _lib.DICE_BLOCKS, dtype=torch.float32, device=x.device)
+            scratch = _dice_scratch[key] = torch.zeros(3 * _lib.DICE_BLOCKS, dtype=torch.float32, device=x.device)
     check(_lib.load().cvx_conv3_out_fused(x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), _p(labels), _p(dice),
                                           _p(scratch), D, H, W, _stream()), "cvx_conv3_out_fused")
 

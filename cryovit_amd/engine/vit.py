@@ -189,6 +189,14 @@ class VitEngine:
             blocks.append(blk)
         self.w, self.blocks = w, blocks
 
+    def clone_for_stream(self) -> "VitEngine":
+        """A second launch context over the SAME packed weights with its own workspaces -- one per HIP stream, so two slice
+        batches (or two volumes) can be in flight at once and fill each other's tails / epilogue bubbles."""
+        other = object.__new__(VitEngine)
+        other.__dict__.update(self.__dict__)
+        other._ws = {}
+        return other
+
     def weight_bytes(self) -> int:
         n = sum(t.numel() * t.element_size() for t in self.w.values())
         return n + sum(t.numel() * t.element_size() for b in self.blocks for t in b.values())

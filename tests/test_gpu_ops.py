@@ -140,8 +140,20 @@ def test_layernorm(gpu, C):
     assert torch.allclose(out.float().cpu(), ref, atol=2e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3)])
-def test_attention(gpu, nt, slices, heads):
+@pytest.fixture
+def attn_variant(request):
+    """All attention kernels kept in attention.hip are parity-tested: 0 = 32 query rows per wave (4-wave blocks),
+    3 = three K/V buffers, 4 / 5 = 64 query rows per wave in 3- / 4-wave blocks."""
+    from cryovit_amd import _lib
+
+    _lib.set_option("attn_variant", request.param)
+    yield request.param
+    _lib.set_option("attn_variant", 0)
+
+
+@pytest.mark.parametrize("attn_variant", [0, 3, 4, 5], indirect=True)
+@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1)])
+def test_attention(gpu, nt, slices, heads, attn_variant):
     from cryovit_amd.engine import ops
 
     C = heads * 64
@@ -167,7 +179,8 @@ def test_attention(gpu, nt, slices, heads):
     assert torch.all(got[:, nt:] == 0), "padding rows must not be written"
 
 
-def test_attention_forced_rescale(gpu):
+@pytest.mark.parametrize("attn_variant", [0, 4], indirect=True)
+def test_attention_forced_rescale(gpu, attn_variant):
     """One key row spiked against one query so the running max jumps in a late tile (rare-branch test)."""
     from cryovit_amd.engine import ops
 
