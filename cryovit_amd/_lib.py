@@ -40,6 +40,21 @@ class Conv3dDesc(C.Structure):
     ]
 
 
+class VitLayer(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "qk_w", "qk_b", "v_w", "v_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b",
+                                        "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b", "ls2")]
+
+
+class VitDesc(C.Structure):
+    _fields_ = [("dim", c_int), ("depth", c_int), ("heads", c_int), ("n_reg", c_int), ("ffn_swiglu", c_int), ("hid_pad", c_int),
+                ("ln_eps", c_float), ("pe_b", c_void_p), ("reg", c_void_p), ("norm_w", c_void_p), ("norm_b", c_void_p),
+                ("layers", C.POINTER(VitLayer))]
+
+
+class VitWs(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("x", "xn", "qk", "vt", "ao", "hid")]
+
+
 # name -> (restype, argtypes); every symbol include/cryovit_hip.h declares
 SIGNATURES = {
     "cvx_last_error": (C.c_char_p, []),
@@ -48,6 +63,8 @@ SIGNATURES = {
     "cvx_set_option": (c_int, [C.c_char_p, c_int]),
     "cvx_debug_read_gemm256": (c_int, [c_void_p]),
     "cvx_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
+    "cvx_set_gemm_event_hook": (c_int, [c_int, c_void_p, c_void_p, c_int]),
+    "cvx_get_gemm_event_count": (c_int, []),
     "cvx_conv3d_bf16": (c_int, [C.POINTER(Conv3dDesc), c_void_p]),
     "cvx_layernorm_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
     "cvx_attention_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -61,6 +78,8 @@ SIGNATURES = {
     "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_int, c_void_p]),
     "cvx_dice_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
+    "cvx_vit_encode": (c_int, [C.POINTER(VitDesc), C.POINTER(VitWs), c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

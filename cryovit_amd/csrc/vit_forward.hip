@@ -1,0 +1,72 @@
+// cvx_vit_encode / cvx_head_forward: the two hot-path calls as single C-ABI entry points.  They are launch sequences
+// over the op-level kernels (no allocation, no synchronisation, caller's stream: hipGraph-capturable); weights and
+// workspaces are caller-owned device buffers described by plain structs.
+#include "../../include/cryovit_hip.h"
+#include "host_util.h"
+
+#define CVX_TRY(expr)            \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc) return _rc;     \
+    } while (0)
+
+static cvx_gemm_desc gemm_base(int epi, const void* a, long lda, const void* w, long ldw, long m, long n, long n_pad, long k_pad,
+                               void* out, long ldc, const float* bias) {
+    cvx_gemm_desc d = {};
+    d.epilogue = epi; d.a = a; d.lda = lda; d.w = w; d.ldw = ldw; d.m = m; d.n = n; d.n_pad = n_pad; d.k_pad = k_pad;
+    d.out = out; d.ldc = ldc; d.bias = bias;
+    return d;
+}
+static long rup(long x, long m) { return (x + m - 1) / m * m; }
+
+extern "C" int cvx_vit_encode(const cvx_vit_desc* v, const cvx_vit_ws* ws, int b, int hp, int wp, const void* patches, long patches_ld,
+                              const void* pe_w, const float* pos, const float* cls_pos0, void* feats_f16, long d_total, long d0,
+                              void* feats_cl, float* tokens_f32, hipStream_t st) {
+    if (!v || !ws || !v->layers) return cvx_fail("vit_encode: null descriptor");
+    if (b <= 0) return 0;
+    if (v->dim % 128 || v->dim / v->heads != 64 || v->dim % v->heads) return cvx_fail("vit_encode: dim must be heads*64 and a multiple of 128");
+    const int C = v->dim, npatch = hp * wp, tok0 = 1 + v->n_reg, nt = npatch + tok0;
+    const int ntp = (int)rup(nt, 8), kp = (int)rup(nt, 64);
+    const long M = (long)b * ntp;
+    const long c128 = rup(C, 128), c2 = rup(2L * C, 128);
+    CVX_TRY(cvx_init_tokens((float*)ws->x, C, cls_pos0, v->reg, v->n_reg, b, nt, ntp, C, st));
+    {
+        cvx_gemm_desc d = gemm_base(CVX_EPI_PATCH, patches, patches_ld, pe_w, patches_ld, (long)b * npatch, C, c128, patches_ld, ws->x, C, v->pe_b);
+        d.pos = pos; d.ldpos = C; d.npatch = npatch; d.ntp = ntp; d.tok0 = tok0;
+        CVX_TRY(cvx_gemm_bf16(&d, st));
+    }
+    for (int i = 0; i < v->depth; ++i) {
+        const cvx_vit_layer* L = &v->layers[i];
+        CVX_TRY(cvx_layernorm_bf16((const float*)ws->x, C, L->ln1_w, L->ln1_b, ws->xn, C, M, C, v->ln_eps, st));
+        {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_BF16, ws->xn, C, L->qk_w, C, M, 2L * C, c2, C, ws->qk, 2L * C, L->qk_b);
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_VT, ws->xn, C, L->v_w, C, M, C, c128, C, ws->vt, 0, L->v_b);
+            d.heads = v->heads; d.ntp = ntp; d.kp = kp;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        CVX_TRY(cvx_attention_bf16(ws->qk, 2L * C, ws->vt, ws->ao, C, b, v->heads, nt, ntp, kp, st));
+        {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_RESID, ws->ao, C, L->proj_w, C, M, C, c128, C, ws->x, C, L->proj_b);
+            d.gamma = L->ls1;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        CVX_TRY(cvx_layernorm_bf16((const float*)ws->x, C, L->ln2_w, L->ln2_b, ws->xn, C, M, C, v->ln_eps, st));
+        if (v->ffn_swiglu) {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_SWIGLU, ws->xn, C, L->ffn1_w, C, M, 2L * v->hid_pad, 2L * v->hid_pad, C, ws->hid, v->hid_pad, L->ffn1_b);
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        } else {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_BF16_GELU, ws->xn, C, L->ffn1_w, C, M, v->hid_pad, v->hid_pad, C, ws->hid, v->hid_pad, L->ffn1_b);
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_RESID, ws->hid, v->hid_pad, L->ffn2_w, v->hid_pad, M, C, c128, v->hid_pad, ws->x, C, L->ffn2_b);
+            d.gamma = L->ls2;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+    }
+    return cvx_final_norm_features((const float*)ws->x, C, v->norm_w, v->norm_b, v->ln_eps, b, ntp, tok0, hp, wp, C, feats_f16, d_total, d0,
+                                   feats_cl, tokens_f32, st);
+}

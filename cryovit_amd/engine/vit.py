@@ -264,7 +264,42 @@ class VitEngine:
         self._encode(b, hp, wp, ws["ape"], self.w["pe3_w"], None, 0, 0, None, tokens)
         return {"x_norm_patchtokens": tokens}
 
+    def _c_desc(self):
+        """ctypes view of the packed weights for cvx_vit_encode (built once; keeps the arrays alive)."""
+        if getattr(self, "_cdesc", None) is None:
+            from cryovit_amd._lib import VitDesc, VitLayer
+
+            layers = (VitLayer * self.cfg.depth)()
+            for i, blk in enumerate(self.blocks):
+                for name in ("ln1_w", "ln1_b", "qk_w", "qk_b", "v_w", "v_b", "proj_w", "proj_b", "ls1", "ln2_w", "ln2_b", "ffn1_w",
+                             "ffn1_b", "ffn2_w", "ffn2_b", "ls2"):
+                    setattr(layers[i], name, blk[name].data_ptr())
+            d = VitDesc(dim=self.cfg.dim, depth=self.cfg.depth, heads=self.cfg.heads, n_reg=self.cfg.n_reg,
+                        ffn_swiglu=int(self.cfg.ffn == "swiglu"), hid_pad=self.hid_pad, ln_eps=self.cfg.ln_eps,
+                        pe_b=self.w["pe_b"].data_ptr(), reg=self.w["reg"].data_ptr(), norm_w=self.w["norm_w"].data_ptr(),
+                        norm_b=self.w["norm_b"].data_ptr(), layers=layers)
+            self._cdesc = (d, layers)
+        return self._cdesc[0]
+
     def _encode(self, b, hp, wp, ape, pe_w, feats_f16, d_total, d0, feats_cl, tokens_f32) -> None:
+        """One C-ABI call for the whole encoder (cvx_vit_encode); `_encode_py` below is the same launch list in Python."""
+        import ctypes as C
+
+        from cryovit_amd import _lib
+        from cryovit_amd._lib import VitWs
+
+        ws = self._workspace(b, hp, wp)
+        pos, cls_pos0 = self._pos_for(hp, wp)
+        cws = VitWs(x=ws["x"].data_ptr(), xn=ws["xn"].data_ptr(), qk=ws["qk"].data_ptr(), vt=ws["vt"].data_ptr(),
+                    ao=ws["ao"].data_ptr(), hid=ws["hid"].data_ptr())
+        p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        for t in (ape, pe_w, feats_f16, feats_cl, tokens_f32):
+            ops._dev_check(t)
+        _lib.check(_lib.load().cvx_vit_encode(C.byref(self._c_desc()), C.byref(cws), b, hp, wp, ape.data_ptr(), ape.stride(0),
+                                              pe_w.data_ptr(), pos.data_ptr(), cls_pos0.data_ptr(), p(feats_f16), d_total, d0,
+                                              p(feats_cl), p(tokens_f32), ops._stream()), "cvx_vit_encode")
+
+    def _encode_py(self, b, hp, wp, ape, pe_w, feats_f16, d_total, d0, feats_cl, tokens_f32) -> None:
         cfg = self.cfg
         _, _, nt, ntp, kp = self._geometry(hp, wp)
         C, npatch, tok0 = cfg.dim, hp * wp, 1 + cfg.n_reg

@@ -5,10 +5,12 @@
  * header is therefore the boundary a maintainer would bind with ctypes to replace the third-party
  * arithmetic the reference delegates to torch / xformers / the dinov2 hub model:
  *
- *   cvx_vit_forward   replaces  model.forward_features(vec)["x_norm_patchtokens"] + reshape/permute/half
- *                               src/cryovit/run/dino_features.py:53-61  (and the CPU bicubic resize of
- *                               src/cryovit/datasets/vit_dataset.py:117-123, which it fuses)
- *   cvx_head_forward  replaces  CryoVIT.forward_volume + sigmoid          src/cryovit/models/cryovit.py:36-49
+ *   cvx_preprocess_patches + cvx_vit_encode
+ *                     replace   model.forward_features(vec)["x_norm_patchtokens"] + reshape/permute/half
+ *                               src/cryovit/run/dino_features.py:53-61  and the CPU bicubic resize of
+ *                               src/cryovit/datasets/vit_dataset.py:117-123 (fused into the first kernel)
+ *   the head launch list (cvx_gemm_bf16, cvx_groupnorm_bf16, cvx_conv3d_bf16, cvx_conv3_out_fused)
+ *                     replaces  CryoVIT.forward_volume + sigmoid          src/cryovit/models/cryovit.py:36-49
  *                               and the masked Dice reductions            src/cryovit/models/base_model.py:99-110,
  *                                                                         src/cryovit/models/metrics.py:30-43
  *
@@ -76,6 +78,11 @@ typedef struct cvx_gemm_desc {
 } cvx_gemm_desc;
 
 int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t stream);
+
+/* Measurement hook: while set, every cvx_gemm_bf16 launch with this epilogue (also inside cvx_vit_encode) is bracketed by
+ * hipEventRecord(start[i]) / hipEventRecord(stop[i]) on the launch stream, i = 0 .. capacity-1.  NULL arrays disable it. */
+int cvx_set_gemm_event_hook(int epilogue, void** start_events, void** stop_events, int capacity);
+int cvx_get_gemm_event_count(void);
 
 /* Dilated 3x3x3 "same" convolution, dilation (dil,1,1), channels-last bf16 volume in[D][H][W][C] ->
  * out[D][H][W][cout] = act(conv + bias), as an implicit GEMM (K = tap*C + c).  w is bf16 [n_pad][k_pad] with
@@ -150,6 +157,48 @@ int cvx_conv3_out_fused(const void* in, const float* w, float bias, float* logit
 
 /* Masked Dice partial sums over existing predictions (same definition as above, threshold thr). */
 int cvx_dice_sums(const float* probs, const int8_t* labels, float* dice, long n, float thr, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The whole DINOv2-with-registers encoder for one slice batch as ONE call: token init + patch-embed
+ * GEMM, `depth` x { LN, QK GEMM, V^T GEMM, attention, proj GEMM (LayerScale+residual), LN, FFN-in GEMM (SwiGLU gate or
+ * GELU), FFN-out GEMM (LayerScale+residual) }, final LN + feature layouts.  Replaces the hub model's forward_features
+ * (run/dino_features.py:58).  All pointers are device buffers owned by the caller; weights are packed as documented for
+ * cvx_gemm_bf16 (Q rows pre-scaled by 1/8; W12 interleaved in blocks of 8 for the SwiGLU variant).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct cvx_vit_layer {
+    const float *ln1_w, *ln1_b;
+    const void* qk_w; const float* qk_b;      /* bf16 [rup(2C,128)][C], fp32 [rup(2C,128)] */
+    const void* v_w; const float* v_b;        /* bf16 [rup(C,128)][C] */
+    const void* proj_w; const float *proj_b, *ls1;
+    const float *ln2_w, *ln2_b;
+    const void* ffn1_w; const float* ffn1_b;  /* SwiGLU: bf16 [2*hid_pad][C] interleaved; MLP: bf16 [hid_pad][C] */
+    const void* ffn2_w; const float *ffn2_b, *ls2; /* bf16 [rup(C,128)][hid_pad] */
+} cvx_vit_layer;
+
+typedef struct cvx_vit_desc {
+    int dim, depth, heads, n_reg, ffn_swiglu, hid_pad;
+    float ln_eps;
+    const float* pe_b;             /* fp32 [rup(C,128)] patch-embed bias */
+    const float* reg;              /* fp32 [n_reg][C] register tokens */
+    const float *norm_w, *norm_b;  /* final LayerNorm */
+    const cvx_vit_layer* layers;   /* HOST array of `depth` entries (device pointers inside) */
+} cvx_vit_desc;
+
+typedef struct cvx_vit_ws {        /* device workspaces, rows = rup(b*ntp,256)+256 (ntp = tokens per slice rounded up to 8) */
+    void* x;    /* fp32 [rows][C]        */
+    void* xn;   /* bf16 [rows][C]        */
+    void* qk;   /* bf16 [rows][2C]       */
+    void* vt;   /* bf16 [b][heads][64][kp], zero-initialised once (kp = tokens rounded up to 64) */
+    void* ao;   /* bf16 [rows][C], zero-initialised once */
+    void* hid;  /* bf16 [rows][hid_pad]  */
+} cvx_vit_ws;
+
+/* patches: bf16 [rup(b*hp*wp,256)+256][patches_ld] from cvx_preprocess_patches (patches_ld = 256, pe_w = channel-summed
+ * kernel [rup(C,128)][256]) or cvx_im2col_patches (patches_ld = 640, pe_w [rup(C,128)][640]); pos fp32 [1+hp*wp][C]
+ * (interpolated position table), cls_pos0 fp32 [C] = cls_token + pos[0].  Outputs as in cvx_final_norm_features. */
+int cvx_vit_encode(const cvx_vit_desc* vit, const cvx_vit_ws* ws, int b, int hp, int wp, const void* patches, long patches_ld,
+                   const void* pe_w, const float* pos, const float* cls_pos0, void* feats_f16, long d_total, long d0,
+                   void* feats_cl, float* tokens_f32, hipStream_t stream);
 
 #ifdef __cplusplus
 }
