@@ -239,3 +239,36 @@ def test_full_size_properties(gpu):
     assert torch.equal(out["dice_sums"].cpu(), want), (out["dice_sums"].cpu(), want)
     fg = float((p >= 0.5).float().mean())
     assert 0.05 < fg < 0.95, f"degenerate synthetic head (fg fraction {fg})"
+
+
+def test_head_full_width_midsize_vs_oracle(gpu):
+    """BASELINE configs[2] at reduced extent: the FULL-WIDTH head (1536 -> 1024 -> ... -> 1, all four dilation pairs)
+    on features [1536, 40, 8, 6] -> 40 x 128 x 96 voxels against the fp32 CPU oracle: logits and masked Dice.
+    Depth 40 > the largest dilation (32), so taps at z +- 32 are exercised both inside and outside the volume."""
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import HeadEngine
+    from oracle import dice as od
+    from oracle import head as oh
+    from oracle.make_golden import synth_labels
+
+    head = oh.CryoVITHead()
+    oh.rescaled_init_(head, seed=5)
+    C, D, h, w = 1536, 40, 8, 6
+    feats = torch.randn(C, D, h, w, generator=torch.Generator().manual_seed(3)).half()
+    with torch.inference_mode():
+        ref = head.forward_volume(feats.float().unsqueeze(0))[0, 0]
+    eng = HeadEngine(head.state_dict(), gpu)
+    cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.bfloat16, device=gpu)
+    ops.features_to_channels_last(feats.to(gpu), cl)
+    labels = torch.from_numpy(synth_labels(D, 16 * h, 16 * w, seed=4))
+    out = eng.forward(cl, D, h, w, labels=labels.to(gpu), want_logits=True)
+    got = out["logits"].cpu()
+    err = (got - ref).abs()
+    assert float(err.max()) <= 2.5e-1 and float(err.mean()) <= 2e-2, (float(err.max()), float(err.mean()))
+    i, sy, sp = out["dice_sums"].cpu().tolist()
+    dice = 2 * i / (sy + sp + 1e-3)
+    want = od.dice_metric(torch.sigmoid(ref), labels.float())
+    flips = int((((got > 0) != (ref > 0)) & (labels > -1)).sum())
+    assert abs(dice - want) <= 1e-3, (dice, want, f"{flips} labelled voxels changed side of the threshold")
+    fg = float((ref > 0).float().mean())
+    assert 0.05 < fg < 0.95
