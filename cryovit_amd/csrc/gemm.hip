@@ -6,6 +6,8 @@
 #include "host_util.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
+#include <utility>
 
 namespace cvx {
 
@@ -70,6 +72,17 @@ struct EpiBF16 {
         }
         store_bf16_chunked<NV>(out + m * ldc + n0, v, n0, n_valid);
     }
+    // the same epilogue for rows [m_off, ...) of the problem when A is passed advanced by m_off rows (tail launches)
+    EpiBF16 shifted(long m_off) const { return EpiBF16{out + m_off * ldc, ldc, bias, m_valid - m_off, n_valid}; }
+    // LDS-staged row-major store (gemm256.h): 16 accumulators -> OUT16 packed bf16 outputs of column n0 >> OUT_SHIFT
+    static constexpr int OUT16 = 16, OUT_SHIFT = 0;
+    __device__ __forceinline__ void produce(const Ctx<16>& c, const float* acc, uint32_t (&w)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float a = acc[2 * i] + c.bias[2 * i], b = acc[2 * i + 1] + c.bias[2 * i + 1];
+            w[i] = pack2bf(ACT == 1 ? gelu_erf(a) : a, ACT == 1 ? gelu_erf(b) : b);
+        }
+    }
 };
 
 // SwiGLU gate: packed W12 rows are interleaved in blocks of 8 (a[8j..8j+7], b[8j..8j+7]) so a lane's 16
@@ -88,6 +101,14 @@ struct EpiSwiGLU {
         for (int i = 0; i < 8; ++i) v[i] = silu(acc[i] + c.bias[i]) * (acc[8 + i] + c.bias[8 + i]);
         store_bf16_chunked<8>(out + m * ldc + (n0 >> 1), v, 0, 1);
     }
+    EpiSwiGLU shifted(long m_off) const { return EpiSwiGLU{out + m_off * ldc, ldc, bias, m_valid - m_off, n_valid}; }
+    static constexpr int OUT16 = 8, OUT_SHIFT = 1;  // 8 gated outputs per 16 accumulators, output column = n0 / 2
+    __device__ __forceinline__ void produce(const Ctx<16>& c, const float* acc, uint32_t (&w)[4]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = pack2bf(silu(acc[2 * i] + c.bias[2 * i]) * (acc[8 + 2 * i] + c.bias[8 + 2 * i]),
+                           silu(acc[2 * i + 1] + c.bias[2 * i + 1]) * (acc[9 + 2 * i] + c.bias[9 + 2 * i]));
+    }
 };
 
 // residual stream update in fp32:  x[m][n] += gamma[n] * (acc + bias[n])
@@ -102,6 +123,7 @@ struct EpiResid {
     // the residual values are PRE-LOADED for a batch of output columns before any of them is stored: issued one after
     // the other, each load -> add -> store round trip exposed a full HBM latency (32 per lane per tile: the epilogue
     // took as long as the whole K loop of the proj GEMM -- tools/stamp_gemm_coarse.py)
+    EpiResid shifted(long m_off) const { return EpiResid{x + m_off * ldx, ldx, bias, gamma, m_valid - m_off, n_valid}; }
     static constexpr bool HAS_PRELOAD = true;
     template <int NV> struct Pre { float4 x[NV / 4]; };
     template <int NV>
@@ -164,7 +186,8 @@ struct EpiPatch {
 // V written TRANSPOSED for the attention kernel (MREG orientation: a lane owns NV consecutive tokens of one
 // feature n = head*64 + d):   vt[slice][head][d][t] = acc + bias[n],   token row m = slice*ntp + t
 struct EpiVT {
-    uint16_t* vt; const float* bias; int heads, ntp, kp; long m_valid, n_valid;
+    uint16_t* vt; const float* bias; int heads, ntp, kp; long m_valid, n_valid; long m_off = 0;  // m_off: row of the problem that A row 0 is
+    EpiVT shifted(long off) const { EpiVT e = *this; e.m_off = m_off + off; e.m_valid = m_valid - off; return e; }
     template <int NV> struct Ctx {};
     template <int NV>
     __device__ __forceinline__ void prep(Ctx<NV>&, long) const {}
@@ -176,8 +199,8 @@ struct EpiVT {
         const long head = n >> 6, d = n & 63;
 #pragma unroll
         for (int h = 0; h < NV / 8; ++h) {
-            const long m8 = m0 + h * 8;
-            if (m8 >= m_valid) continue;
+            if (m0 + h * 8 >= m_valid) continue;
+            const long m8 = m0 + h * 8 + m_off;
             const long s = m8 / ntp, t = m8 - s * ntp;  // ntp % 8 == 0: a group of 8 never straddles slices
             float v[8];
 #pragma unroll
@@ -325,6 +348,7 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             case 5: k = k_gemm256_nreg<Epi, 5>; break;
             case 6: k = k_gemm256_nreg<Epi, 6>; break;
             case 7: k = k_gemm256_nreg<Epi, 7>; break;
+            case 8: k = k_gemm256_nreg<Epi, 8>; break;
             case 20: k = k_gemm256_nreg<Epi, 20>; break;
             case 21: k = k_gemm256_nreg<Epi, 21>; break;
             case 10: k = k_gemm256_nreg<Epi, 10>; break;
@@ -343,6 +367,20 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
     return cvx_check_launch();
 }
 
+template <class E, class = void> struct epi_can_shift : std::false_type {};
+template <class E> struct epi_can_shift<E, std::void_t<decltype(std::declval<const E&>().shifted(0L))>> : std::true_type {};
+
+// Tail split: a 256-tile grid whose last round would keep only a few CUs busy (e.g. 3096 tiles = 12 rounds + 24 tiles for
+// the N = 1536 GEMMs of one 128-slice batch) is cut into a main launch of whole rounds and a tail launch over the remaining
+// M rows with 128x128 tiles (4x as many, quarter-size tiles: the tail costs ~0.3 of a round instead of a full one).
+static int g_tail_split = 1;
+static long tail_split_rows(long M, long Npad, bool allow = true) {
+    const long tiles_n = Npad / 256, tiles_m = (M + 255) / 256, tiles = tiles_n * tiles_m, rem = tiles % 256;
+    if (!g_tail_split || !allow || tiles < 512 || rem == 0 || rem > 64) return M;
+    const long main_mtiles = (tiles - rem) / tiles_n;
+    return main_mtiles > 0 ? main_mtiles * 256 : M;
+}
+
 template <class Cfg, class Epi>
 static int launch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad,
                        const Epi& epi, hipStream_t st) {
@@ -354,11 +392,28 @@ static int launch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw
     return cvx_check_launch();
 }
 
+// 256-tile launch with the tail split (NREG epilogues that can be re-based on a row offset)
+template <class Epi>
+static int launch_256_split(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad, const Epi& epi,
+                            hipStream_t st) {
+    if constexpr (epi_can_shift<Epi>::value) {
+        // (the 128-tile kernel's fp32 read-modify-write epilogue is not LDS-staged: with a short K loop the tail would cost
+        //  more than the idle round it removes -- measured on the proj GEMM)
+        const long m_main = tail_split_rows(M, Npad, !epi_has_preload<Epi>::value || Kpad >= 2048);
+        if (m_main < M) {
+            int rc = launch_256<Epi, false>(A, lda, Wt, ldw, m_main, Npad, Kpad, epi, st);
+            if (rc) return rc;
+            return launch_nreg<TileCfg<128, 128, 2>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
+        }
+    }
+    return launch_256<Epi, false>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+}
+
 template <class Epi>
 static int dispatch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad,
                          const Epi& epi, hipStream_t st) {
     if (Kpad % BK) return cvx_fail("gemm: K must be padded to a multiple of 64");
-    if (use_gemm256(M, Npad, Kpad)) return launch_256<Epi, false>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+    if (use_gemm256(M, Npad, Kpad)) return launch_256_split(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 128 == 0) return launch_nreg<TileCfg<128, 128, 2>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 64 == 0) return launch_nreg<TileCfg<64, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 32 == 0) return launch_nreg<TileCfg<32, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
@@ -394,6 +449,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
     if (!strcmp(name, "use_gemm256")) g_use_gemm256 = value;
     else if (!strcmp(name, "gemm256_variant")) g_gemm256_variant = value;
     else if (!strcmp(name, "gemm_stagger")) g_gemm_stagger = value;
+    else if (!strcmp(name, "gemm_tail_split")) g_tail_split = value;
     else if (!strcmp(name, "attn_variant")) g_attn_variant = value;
     else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value;
     else if (!strcmp(name, "tile_group_l")) {
@@ -447,8 +503,7 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         case CVX_EPI_SWIGLU: {
             if (d->n_pad % 128) return cvx_fail("gemm: SwiGLU needs N padded to 128");
             EpiSwiGLU e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
-            if (use_gemm256(d->m, d->n_pad, d->k_pad))
-                return launch_256<EpiSwiGLU, false>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            if (use_gemm256(d->m, d->n_pad, d->k_pad)) return launch_256_split(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
             return launch_nreg<TileCfg<128, 128, 2>>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_RESID: {
@@ -462,15 +517,22 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         case CVX_EPI_VT: {
             if (d->n_pad % 128 || d->k_pad % BK) return cvx_fail("gemm: V^T epilogue needs N padded to 128, K to 64");
             EpiVT e{(uint16_t*)d->out, d->bias, d->heads, d->ntp, d->kp, d->m, d->n};
-            if (use_gemm256(d->m, d->n_pad, d->k_pad))
-                return launch_256<EpiVT, true>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
             using Cfg = TileCfg<128, 128, 2>;
-            const int tiles_n = (int)(d->n_pad / Cfg::BL), tiles_m = (int)((d->m + Cfg::BR - 1) / Cfg::BR);
-            auto k = k_gemm_mreg<Cfg, EpiVT>;
-            CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-            hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, A, d->lda, W, d->ldw,
-                               (int)(d->k_pad / BK), tiles_n, tiles_m, e);
-            return cvx_check_launch();
+            auto tail128 = [&](const uint16_t* a, long m, const EpiVT& ev) {
+                const int tiles_n = (int)(d->n_pad / Cfg::BL), tiles_m = (int)((m + Cfg::BR - 1) / Cfg::BR);
+                auto k = k_gemm_mreg<Cfg, EpiVT>;
+                CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+                hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, a, d->lda, W, d->ldw,
+                                   (int)(d->k_pad / BK), tiles_n, tiles_m, ev);
+                return cvx_check_launch();
+            };
+            if (use_gemm256(d->m, d->n_pad, d->k_pad)) {
+                const long m_main = tail_split_rows(d->m, d->n_pad);
+                int rc = launch_256<EpiVT, true>(A, d->lda, W, d->ldw, m_main, d->n_pad, d->k_pad, e, st);
+                if (rc || m_main == d->m) return rc;
+                return tail128(A + m_main * d->lda, d->m - m_main, e.shifted(m_main));
+            }
+            return tail128(A, d->m, e);
         }
         case CVX_EPI_CONVT: {
             if (d->cout % 8) return cvx_fail("gemm: ConvT C_out must be a multiple of 8");

@@ -34,6 +34,8 @@ constexpr int G256_THREADS = 512;
 constexpr int G256_HALF_BYTES = 128 * 128;            // 128 rows x 64 bf16
 constexpr int G256_LDS_BYTES = 8 * G256_HALF_BYTES;   // ring of 8 half-tiles
 
+template <class E, class = void> struct epi_has_produce : std::false_type {};
+template <class E> struct epi_has_produce<E, std::enable_if_t<(E::OUT16 > 0)>> : std::true_type {};
 template <class E, class = void> struct epi_has_preload : std::false_type {};
 template <class E> struct epi_has_preload<E, std::enable_if_t<E::HAS_PRELOAD>> : std::true_type {};
 
@@ -195,7 +197,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
         for (; t < nk; ++t) ktile(t, std::false_type{});
     }
     if (wl == 0) __builtin_amdgcn_s_barrier();
-    } else if constexpr (VARIANT == 0 || VARIANT == 4 || VARIANT == 5 || VARIANT >= 10) {
+    } else if constexpr (VARIANT == 0 || VARIANT == 4 || VARIANT == 5 || VARIANT == 8 || VARIANT >= 10) {
     // ---- variants 0/4/5: reads at rd(q) in {q-1,q}, 3-4 half-tiles in flight (A = 5) ----
     bf16x8 rlo[2][2], rhi[2][2], lf[4][2];  // [frag][k-step]
 
@@ -235,7 +237,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     // one K tile.  STEADY: all four DMA issues exist -> unconditional issue + exact counted waits (no branches).
     // ISSUE_IN_MMA: the DMA is issued from the MFMA segment (in the issue gaps of the wave's own MFMAs) instead of the
     // load segment, which is the critical one (it competes for issue slots with the partner wave's MFMA stream).
-    constexpr bool ISSUE_IN_MMA = (VARIANT == 5 || VARIANT == 21);
+    constexpr bool ISSUE_IN_MMA = (VARIANT == 5 || VARIANT == 8 || VARIANT == 21);  // 8 = 5 with the un-staged bf16 epilogue (A/B)
     auto ktile = [&](int t, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         const char* st = smem + (t & 1) * 4 * G256_HALF_BYTES;
@@ -439,6 +441,42 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
                     o.x = xv[i].x + d.x; o.y = xv[i].y + d.y; o.z = xv[i].z + d.z; o.w = xv[i].w + d.w;
                     *(float4*)(epi.x + m * epi.ldx + nglob) = o;
                 }
+            }
+        }
+    } else if constexpr (epi_has_produce<Epi>::value && VARIANT != 8) {
+        // bf16 row-major epilogues, staged through LDS like the fp32 one: in accumulator layout every 16-B store of a wave
+        // instruction lands in a different half-used cache line (16 rows x 4 pieces); staged, an instruction writes whole
+        // 128-B (BF16) / 64-B (SwiGLU) row segments.  Per wave: 32 rows x (ROWB + 16) bytes of the idle DMA ring.
+        constexpr int O16 = Epi::OUT16, ROWB = 4 * O16 * 2, PITCHB = ROWB + 16, LPR = ROWB / 16, RPI = 64 / LPR;
+        char* stg = smem + wave * 32 * PITCHB;
+        const int srow = lane / LPR, spiece = lane % LPR;
+        const long ocol = ((r0 + wr * 64) >> Epi::OUT_SHIFT) + spiece * 8;       // first output column of this lane's 16 B
+        const long ovalid = epi.n_valid >> Epi::OUT_SHIFT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                float v[16];
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][2 * q + bb][e];
+                uint32_t w[O16 / 2];
+                epi.produce(ctx, v, w);
+                char* dst = stg + (16 * bb + (lane & 15)) * PITCHB + gq * (O16 * 2);
+                if constexpr (O16 == 16) {
+                    *(uint4*)dst = uint4{w[0], w[1], w[2], w[3]};
+                    *(uint4*)(dst + 16) = uint4{w[4], w[5], w[6], w[7]};
+                } else {
+                    *(uint4*)dst = uint4{w[0], w[1], w[2], w[3]};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 32 / RPI; ++i) {
+                const int row = RPI * i + srow;
+                const long m = l0 + wl * 128 + 32 * q + row;
+                const uint4 d = *(const uint4*)(stg + row * PITCHB + spiece * 16);
+                if (m < epi.m_valid && ocol < ovalid) *(uint4*)(epi.out + m * epi.ldc + ocol) = d;
             }
         }
     } else {

@@ -354,7 +354,7 @@ DEFAULT_GEMM = (1, 5)  # (tile kernel: 1 = 8-wave gemm256.h, 2 = 4-wave gemm4w.h
 
 
 @pytest.mark.parametrize("gemm256_variant", [(1, 0), (1, 1), (1, 5), (1, 6), (2, 0)], indirect=True)
-@pytest.mark.parametrize("M,N,K", [(1029 * 2 + 7, 512, 256), (3000, 256, 1536), (2048, 1536, 4096)])
+@pytest.mark.parametrize("M,N,K", [(1029 * 2 + 7, 512, 256), (3000, 256, 1536), (2048, 1536, 4096), (66500, 512, 256)])
 def test_gemm256_bf16_and_resid(gpu, M, N, K, gemm256_variant):
     from cryovit_amd._lib import EPI_BF16, EPI_RESID
     from cryovit_amd.engine import ops
@@ -372,9 +372,10 @@ def test_gemm256_bf16_and_resid(gpu, M, N, K, gemm256_variant):
     x[:M] = x0.to(gpu)
     ops.gemm(EPI_RESID, A, Wd, x, b.to(gpu), m=M, n=N, gamma=gm.to(gpu))
     assert torch.allclose(x[:M].cpu(), x0 + gm * ref, atol=2e-4, rtol=1e-4)
+    # (M = 66500: 260 x 2 = 520 tiles -> the launch is cut into 2 whole rounds of 256x256 tiles + a 128x128-tile tail)
     # race screen: the pipeline's waits/barriers are hand-counted -- repeated launches must be bit-identical
     outs = []
-    for _ in range(8):
+    for _ in range(8 if M < 10000 else 2):
         o = torch.zeros(ops.alloc_rows(M), N, dtype=torch.bfloat16, device=gpu)
         ops.gemm(EPI_BF16, A, Wd, o, b.to(gpu), m=M, n=N)
         outs.append(o)
@@ -422,3 +423,32 @@ def test_gemm256_swiglu_vt_patch(gpu, gemm256_variant):
     got = x[: bp * ntpp].cpu().reshape(bp, ntpp, Cp)
     assert torch.allclose(got[:, 1 + n_reg : ntk], pe, atol=1e-4, rtol=1e-4)
     assert torch.all(got[:, :1 + n_reg] == 0) and torch.all(got[:, ntk:] == 0)
+
+
+def test_gemm256_tail_split_vt_swiglu(gpu):
+    """Tail split (whole rounds of 256-tiles + a 128-tile tail over the last rows) for the V^T and SwiGLU epilogues."""
+    from cryovit_amd._lib import EPI_SWIGLU, EPI_VT
+    from cryovit_amd.engine import ops
+
+    K = 256
+    b_, heads, nt = 260, 4, 250  # ntp = 256 -> M = 66560 rows = 260 M-tiles; N = 256 -> 260 tiles ... use N = 512 via 8 heads
+    heads = 8
+    ntp, kp, C = 256, 256, heads * 64
+    Mv = b_ * ntp
+    av, wv, bv = rnd(Mv, K, seed=81), rnd(C, K, seed=82, scale=K**-0.5), rnd(C, seed=83)
+    vt = torch.zeros(b_, heads, 64, kp, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_VT, padded_bf16(av, ops.alloc_rows(Mv), K, gpu), padded_bf16(wv, C, K, gpu), vt, bv.to(gpu), m=Mv, n=C, heads=heads,
+             ntp=ntp, kp=kp, ldc=0)
+    v = (bf(av).float() @ bf(wv).float().T + bv).reshape(b_, ntp, heads, 64).permute(0, 2, 3, 1)
+    assert torch.allclose(vt.float().cpu(), v, atol=2e-2, rtol=1e-2)
+    Hd = 256  # N = 2*Hd = 512
+    w12, b12 = rnd(2 * Hd, K, seed=84, scale=K**-0.5), rnd(2 * Hd, seed=85)
+    iw = torch.stack([w12[:Hd].reshape(-1, 8, K), w12[Hd:].reshape(-1, 8, K)], 1).reshape(2 * Hd, K)
+    ib = torch.stack([b12[:Hd].reshape(-1, 8), b12[Hd:].reshape(-1, 8)], 1).reshape(2 * Hd)
+    M = 66500
+    out = torch.zeros(ops.alloc_rows(M), Hd, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_SWIGLU, padded_bf16(av[:M], ops.alloc_rows(M), K, gpu), bf(iw).to(gpu), out, ib.to(gpu), m=M, n=2 * Hd)
+    h = bf(av[:M]).float() @ bf(w12).float().T + b12
+    ref = F.silu(h[:, :Hd]) * h[:, Hd:]
+    assert torch.allclose(out[:M].float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    assert torch.all(out[M:] == 0)

@@ -51,7 +51,7 @@ def run(name, v, reps=4):
     if groups:
         _lib.set_option("tile_group_l", v)
         v = base_variant
-    _lib.set_option("gemm_stagger", 0 if 1000 <= v < 2000 else 1)  # 1000 + v = schedule v without the first-round stagger
+    _lib.set_option("gemm_tail_split", 0 if 1000 <= v < 2000 else 1)  # 1000 + v = schedule v without the tail split
     v = v - 1000 if 1000 <= v < 2000 else v
     _lib.set_option("use_gemm256", 0 if v == 128 else (2 if v >= 400 else 1))  # 400 + a = 4-wave tile, ablation a
     _lib.set_option("gemm256_variant", 0 if v == 128 else (v - 400 if v >= 400 else v))
