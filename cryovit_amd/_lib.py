@@ -75,8 +75,8 @@ SIGNATURES = {
     "cvx_im2col_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "cvx_features_to_channels_last": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "cvx_groupnorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
-    "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                    c_int, c_void_p]),
+    "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                    c_int, c_int, c_int, c_void_p]),
     "cvx_dice_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
     "cvx_vit_encode": (c_int, [C.POINTER(VitDesc), C.POINTER(VitWs), c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),

@@ -55,9 +55,12 @@ def _merge(dst: dict, src: dict) -> dict:
     return dst
 
 
-def _load(rel: str) -> dict:
+def _load(rel: str, choices: dict[str, str] | None = None, at: str = "") -> dict:
     """Load configs/<rel>.yaml honouring its ``defaults`` list: ``- grp: opt`` pulls <dir of this file>/<grp>/<opt>.yaml
-    in under key ``grp``; ``_self_`` marks where the file's own keys merge (last if absent)."""
+    in under key ``grp``; ``_self_`` marks where the file's own keys merge (last if absent).  ``choices`` maps a group path
+    (``model``, ``datamodule/dataset``) to the option a ``group=option`` override selected; an ``optional`` group whose
+    file does not exist is skipped; a group still at ``???`` stays missing (reported by ``missing_keys``)."""
+    choices = choices or {}
     raw = yaml.safe_load((CONFIG_DIR / f"{rel}.yaml").read_text()) or {}
     defaults = raw.pop("defaults", [])
     out: dict = {}
@@ -70,7 +73,27 @@ def _load(rel: str) -> dict:
             for grp, opt in d.items():
                 if grp.startswith("override "):
                     continue  # hydra's own logging overrides
-                _merge(out, {grp: _load(str(Path(rel).parent / grp / str(opt)))})
+                optional = grp.startswith("optional ")
+                grp = grp.removeprefix("optional ")
+                gpath = f"{at}{grp}"
+                opt = choices.get(gpath, opt)
+                if isinstance(opt, str) and opt.startswith("${") and opt.endswith("}"):
+                    opt = choices.get(opt[2:-1], opt)
+                if isinstance(opt, list):  # "- callbacks: [a, b]": several options merged under the group
+                    sub = {}
+                    for o in opt:
+                        _merge(sub, _load(str(Path(rel).parent / grp / str(o)), choices, f"{gpath}/"))
+                    _merge(out, {grp: sub})
+                    continue
+                if opt == MISSING:
+                    _merge(out, {grp: MISSING})
+                    continue
+                target = str(Path(rel).parent / grp / str(opt))
+                if not (CONFIG_DIR / f"{target}.yaml").exists():
+                    if optional:
+                        continue
+                    raise FileNotFoundError(f"config group {gpath!r} has no option {opt!r}")
+                _merge(out, {grp: _load(target, choices, f"{gpath}/")})
         # bare strings other than _self_ name structured-config schemas in the reference: nothing to load here
     if not self_done:
         _merge(out, raw)
@@ -93,8 +116,11 @@ def _resolve(root: dict, node):
             if not m:
                 break
             cur: Any = root
-            for part in m.group(1).split("."):
-                cur = cur[part]
+            try:
+                for part in m.group(1).split("."):
+                    cur = cur[part]
+            except (KeyError, TypeError):
+                break  # OmegaConf resolves lazily: a dangling reference only matters if somebody reads the key
             cur = _resolve(root, cur)
             node = cur if m.span() == (0, len(node)) else node[: m.start()] + str(cur) + node[m.end() :]
             if not isinstance(node, str):
@@ -102,13 +128,24 @@ def _resolve(root: dict, node):
     return node
 
 
+def _is_group_choice(key: str, val: str) -> bool:
+    """``model=cryovit`` / ``datamodule/dataset=file`` select a config-group option when such a file exists."""
+    return bool(re.fullmatch(r"[\w\-]+", val)) and (CONFIG_DIR / key / f"{val}.yaml").exists()
+
+
 def compose(config_name: str, overrides: list[str] | None = None) -> Cfg:
-    cfg = _load(config_name)
+    choices, sets = {}, []
     for ov in overrides or []:
         if "=" not in ov:
             raise ValueError(f"override {ov!r} is not key=value")
         key, val = ov.split("=", 1)
         key = key.lstrip("+")
+        if _is_group_choice(key, val):
+            choices[key] = val
+        else:
+            sets.append((key, val))
+    cfg = _load(config_name, choices)
+    for key, val in sets:
         node = cfg
         parts = key.split(".")
         for p in parts[:-1]:

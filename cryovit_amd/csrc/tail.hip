@@ -11,8 +11,9 @@ namespace cvx {
 // leave the block as ONE row of `partials` (no same-address atomics: 1.5 M of them cost 19 ms on this volume).
 __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ in, const float* __restrict__ w /*[27][8]*/,
                                                    float bias, float* __restrict__ logits, float* __restrict__ probs,
-                                                   const int8_t* __restrict__ labels, float* __restrict__ partials, int D, int H,
-                                                   int W, int tiles_x, int tiles_y, long ntiles) {
+                                                   const int8_t* __restrict__ labels, float* __restrict__ partials,
+                                                   uint8_t* __restrict__ mask, float mask_thr, int D, int H, int W, int tiles_x,
+                                                   int tiles_y, long ntiles) {
     __shared__ float sw[27 * 8];
     __shared__ float red[3][4];
     for (int i = threadIdx.x; i < 27 * 8; i += 256) sw[i] = w[i];
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ 
         const long v = ((long)z * H + y) * W + x;
         if (logits) logits[v] = lg;
         if (probs) probs[v] = p;
+        if (mask) mask[v] = p >= mask_thr ? 1 : 0;                   // callbacks.py:100-102 (PredictionWriter)
         if (labels) {
             const int lab = labels[v];
             if (lab > -1) {                                          // base_model.py:99
@@ -107,14 +109,15 @@ __global__ __launch_bounds__(256) void k_dice(const float* __restrict__ probs, c
 using namespace cvx;
 
 extern "C" int cvx_conv3_out_fused(const void* in, const float* w, float bias, float* logits, float* probs,
-                                   const int8_t* labels, float* dice, float* scratch, int D, int H, int W, hipStream_t st) {
+                                   const int8_t* labels, float* dice, float* scratch, uint8_t* mask, float mask_threshold, int D,
+                                   int H, int W, hipStream_t st) {
     if (D <= 0 || H <= 0 || W <= 0) return 0;
     if (labels && (!dice || !scratch)) return cvx_fail("conv3_out: labels need a dice accumulator and a scratch buffer");
     const int tiles_x = (W + 63) / 64, tiles_y = (H + 3) / 4;
     const long ntiles = (long)tiles_x * tiles_y * D;
     const int nblk = (int)(ntiles < CVX_DICE_BLOCKS ? ntiles : CVX_DICE_BLOCKS);
-    hipLaunchKernelGGL(k_conv3_out, dim3(nblk), dim3(256), 0, st, (const uint16_t*)in, w, bias, logits, probs, labels, scratch, D,
-                       H, W, tiles_x, tiles_y, ntiles);
+    hipLaunchKernelGGL(k_conv3_out, dim3(nblk), dim3(256), 0, st, (const uint16_t*)in, w, bias, logits, probs, labels, scratch, mask,
+                       mask_threshold, D, H, W, tiles_x, tiles_y, ntiles);
     int rc = cvx_check_launch();
     if (rc || !labels) return rc;
     hipLaunchKernelGGL(k_dice_finalize, dim3(1), dim3(64), 0, st, scratch, nblk, dice);

@@ -118,9 +118,11 @@ class HeadEngine:
             self._ws[key] = torch.zeros(ops.alloc_rows(rows) * ch + 4096, dtype=torch.bfloat16, device=self.device)
         return self._ws[key]
 
-    def forward(self, feats_cl: torch.Tensor, D: int, h: int, w_: int, labels=None, want_logits=False, want_probs=True):
+    def forward(self, feats_cl: torch.Tensor, D: int, h: int, w_: int, labels=None, want_logits=False, want_probs=True,
+                mask_threshold: float | None = None):
         """feats_cl: bf16 channels-last features [D*h*w (+slack rows), C_in].  Returns dict with
-        ``probs`` / ``logits`` fp32 [D, 16h, 16w] and ``dice_sums`` (fp32[3] device tensor) when labels are given."""
+        ``probs`` / ``logits`` fp32 [D, 16h, 16w], ``dice_sums`` (fp32[3] device tensor) when labels are given and
+        ``mask`` uint8 [D, 16h, 16w] = (probs >= mask_threshold) when a threshold is given."""
         c_in, blocks, c_tail = self.widths
         W = self.w
         nvox = D * h * w_
@@ -150,8 +152,10 @@ class HeadEngine:
         dice = None
         if labels is not None:
             dice = torch.zeros(3, dtype=torch.float32, device=self.device)
-        ops.conv3_out_fused(mid, W["o2_w"], self.o2_b, logits, probs, labels, dice, D=D, H=H_, W=W_)
-        out["logits"], out["probs"], out["dice_sums"] = logits, probs, dice
+        mask = torch.empty(D, H_, W_, dtype=torch.uint8, device=self.device) if mask_threshold is not None else None
+        ops.conv3_out_fused(mid, W["o2_w"], self.o2_b, logits, probs, labels, dice, D=D, H=H_, W=W_, mask=mask,
+                            mask_threshold=0.5 if mask_threshold is None else mask_threshold)
+        out["logits"], out["probs"], out["dice_sums"], out["mask"] = logits, probs, dice, mask
         return out
 
     def flops(self, D: int, h: int, w_: int) -> float:

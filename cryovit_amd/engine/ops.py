@@ -133,8 +133,9 @@ def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tens
 _dice_scratch = {}
 
 
-def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs, labels, dice, *, D: int, H: int, W: int) -> None:
-    _dev_check(x, w, logits, probs, labels, dice)
+def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs, labels, dice, *, D: int, H: int, W: int,
+                    mask=None, mask_threshold: float = 0.5) -> None:
+    _dev_check(x, w, logits, probs, labels, dice, mask)
     scratch = None
     if labels is not None:
         key = (x.device, _stream())  # per stream: two volumes may be in flight at once
@@ -142,7 +143,7 @@ def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs
         if scratch is None:
             scratch = _dice_scratch[key] = torch.zeros(3 * _lib.DICE_BLOCKS, dtype=torch.float32, device=x.device)
     check(_lib.load().cvx_conv3_out_fused(x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), _p(labels), _p(dice),
-                                          _p(scratch), D, H, W, _stream()), "cvx_conv3_out_fused")
+                                          _p(scratch), _p(mask), float(mask_threshold), D, H, W, _stream()), "cvx_conv3_out_fused")
 
 
 def dice_sums(probs: torch.Tensor, labels: torch.Tensor, dice: torch.Tensor, thr: float = 0.5) -> None:

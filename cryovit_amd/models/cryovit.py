@@ -90,6 +90,18 @@ class CryoVIT(nn.Module):
         return torch.sigmoid(self.forward_volume(x).squeeze(1))
 
     @torch.inference_mode()
+    def predict_mask(self, batch, threshold: float = 0.5) -> list[Tensor]:
+        """``predict_step`` + ``PredictionWriter``'s threshold (base_model.py:243-273, callbacks.py:100-102): per tomogram
+        the uint8 segmentation ``forward(batch) >= threshold`` [D,H,W], compared inside the head's last kernel."""
+        outs = []
+        for xb in batch.tomo_batch:  # [D,C,h,w]
+            D, C, h, w = xb.shape
+            cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.bfloat16, device=self._device)
+            cl[: D * h * w] = xb.to(self._device).permute(0, 2, 3, 1).reshape(-1, C).to(torch.bfloat16)
+            outs.append(self.engine().forward(cl, D, h, w, want_probs=False, mask_threshold=threshold)["mask"])
+        return outs
+
+    @torch.inference_mode()
     def predict_with_dice(self, feats_cl: Tensor, D: int, h: int, w: int, labels: Tensor | None):
         """Fused inference used by the end-to-end runner: channels-last bf16 features straight from the encoder ->
         probabilities and (with labels) the masked Dice of ``_masked_predict`` + ``DiceMetric``."""

@@ -119,3 +119,46 @@ def run_trainer(cfg) -> None:
     for sample_name in sample_names:
         _process_sample(src_dir, dst_dir, csv_dir, model, sample_name, cfg.datamodule, cfg.batch_size,
                         image_dir if cfg.export_features else None, cfg.use_sam)
+
+
+## For scripts (``cryovit features``)
+
+
+def run_dino(train_data: list[Path], result_dir: Path, batch_size: int, use_sam: bool = False, visualize: bool = False, *,
+             encoder: dict | None = None) -> None:
+    """Feature extraction over a list of tomogram files of any supported format (mirror of l.211-299): one
+    ``<result_dir>/<stem>.hdf`` per input with ``data``, ``dino_features`` and the source's other datasets under ``labels/``.
+    ``encoder`` overrides keys of the config's ``encoder`` block (name / checkpoint / synthetic_seed / device)."""
+    from cryovit_amd.config import compose
+    from cryovit_amd.types import FileData
+
+    if use_sam:
+        raise NotImplementedError("use_sam=True (SAM2 Hiera-L features, BASELINE configs[4]) is a later row of SURVEY s.8f")
+    cfg = compose("dino_features", [f"batch_size={batch_size}", "sample=null", "export_features=False", "datamodule/dataset=file"])
+    enc = dict(cfg.get("encoder", {}) or {})
+    enc.update(encoder or {})
+    rank, local_rank, world = world_info()
+    device = f"cuda:{local_rank}" if world > 1 else enc.get("device", "cuda:0")
+    model = load_encoder(enc.get("name", "dinov2_vitg14_reg"), model_dir=cfg.model_dir, checkpoint=enc.get("checkpoint"),
+                         synthetic_seed=enc.get("synthetic_seed"), device=device).cuda().eval()
+    assert len(train_data) > 0, "No valid tomogram files found in the specified training data path."
+    files = [FileData(tomo_path=Path(f)) for f in train_data]
+    dataset = instantiate(cfg.datamodule.dataset, input_key=None, label_key=None)(files, for_dino=True, use_sam=use_sam)
+    result_list = [Path(result_dir) / f"{Path(f).stem}.hdf" for f in train_data]
+    if visualize:
+        logging.warning("visualize=True: PCA colour maps are plotting (out of scope of this build) -- skipped")
+    try:
+        with ThreadPoolExecutor(max_workers=2) as writer:
+            pending = []
+            for i in shard_records(files, rank, world):
+                x = dataset[i]
+                features = _dino_features(x.data, model, cfg.batch_size)
+                result_path = result_list[i].with_suffix(".hdf")
+                pending.append(writer.submit(_save_data, x.aux_data, features, result_path.name, result_path.parent))
+                while len(pending) > 2:
+                    pending.pop(0).result()
+            for f in pending:
+                f.result()
+    except torch.OutOfMemoryError:
+        print(f"Ran out of GPU memory during DINO feature extraction. Try reducing the batch size. Current batch size is {cfg.batch_size}.")
+        return

@@ -39,6 +39,8 @@ def gather_rows(rows: list, world: int) -> list:
         return list(rows)
     import torch.distributed as dist
 
+    if not dist.is_initialized():  # result rows are host objects: gloo is enough, the data path has no collective
+        dist.init_process_group("gloo")
     out: list = [None] * world
     dist.all_gather_object(out, rows)
     return [r for part in out for r in part]

@@ -38,6 +38,15 @@ def write_prediction(results_dir, tomo_name: str, label_key: str, data: np.ndarr
     return out
 
 
+def write_segmentation(results_dir, tomo_name: str, label_key: str, data: np.ndarray, segs: np.ndarray) -> Path:
+    """``write_prediction`` for a segmentation that was already thresholded on the GPU (uint8 {0,1})."""
+    out = (Path(results_dir) / tomo_name).with_suffix(".hdf")
+    with io.FileWriter(out) as fh:
+        fh.create_dataset("data", data.astype(np.float32), compression="gzip")
+        fh.create_dataset(f"{label_key}_preds", segs.astype(np.uint8, copy=False), compression="gzip")
+    return out
+
+
 def update_metrics_csv(results_dir, sample: str, tomo_name: str, metrics: dict[str, float], split_id=None) -> Path:
     results_dir = Path(results_dir)
     results_dir.mkdir(parents=True, exist_ok=True)

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 from enum import Enum
+from pathlib import Path
 from typing import Any
 
 import numpy as np
@@ -34,10 +35,20 @@ class ModelType(Enum):
 
 
 @dataclass
+class FileData:
+    """File description of one tomogram for the script-level flows (types.py:62-76)."""
+
+    tomo_path: Path
+    label_path: Path | None = None
+    labels: list[str] | None = None
+    sample: str | None = None
+
+
+@dataclass
 class TomogramData:
     """One loaded tomogram (types.py:79-99): ``data`` fp16/fp32 [C,D,h,w] features or [1,D,H,W] raw, ``label`` [D,H,W]."""
 
-    sample: str
+    sample: str | None
     tomo_name: str
     data: torch.Tensor
     label: torch.Tensor

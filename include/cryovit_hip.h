@@ -150,10 +150,13 @@ int cvx_groupnorm_bf16(const void* x, const float* w, const float* b, void* out,
  *   dice[0] += sum(y*p_hat), dice[1] += sum(y), dice[2] += sum(p_hat) over labels > -1, p_hat = (p >= 0.5).
  * Replaces output_layer.2 + clip + sigmoid (cryovit.py:33,39,49) and the reductions of
  * base_model.py:99-110 / metrics.py:36-41.  (output_layer.0 + GELU runs through cvx_conv3d_bf16.)
- * scratch: >= 3*CVX_DICE_BLOCKS floats (per-block partial sums, reduced in a fixed order: reproducible). */
+ * scratch: >= 3*CVX_DICE_BLOCKS floats (per-block partial sums, reduced in a fixed order: reproducible).
+ * mask (nullable): uint8 [D][H][W] = (p >= mask_threshold), the binary segmentation PredictionWriter stores
+ * (src/cryovit/models/callbacks.py:100-102), written here so that only 1 byte per voxel leaves the GPU. */
 #define CVX_DICE_BLOCKS 4096
 int cvx_conv3_out_fused(const void* in, const float* w, float bias, float* logits, float* probs, const int8_t* labels,
-                        float* dice, float* scratch, int D, int H, int W, hipStream_t stream);
+                        float* dice, float* scratch, uint8_t* mask, float mask_threshold, int D, int H, int W,
+                        hipStream_t stream);
 
 /* Masked Dice partial sums over existing predictions (same definition as above, threshold thr). */
 int cvx_dice_sums(const float* probs, const int8_t* labels, float* dice, long n, float thr, hipStream_t stream);

@@ -317,8 +317,11 @@ def test_conv3_out_fused_and_dice(gpu, gold):
     logits = torch.zeros(D, H, W, device=gpu)
     probs = torch.zeros(D, H, W, device=gpu)
     dice = torch.zeros(3, device=gpu)
+    seg = torch.full((D, H, W), 7, dtype=torch.uint8, device=gpu)
     ops.conv3_out_fused(x.to(gpu), w[0].permute(1, 2, 3, 0).reshape(27, 8).contiguous().to(gpu), b, logits, probs, labels.to(gpu),
-                        dice, D=D, H=H, W=W)
+                        dice, D=D, H=H, W=W, mask=seg, mask_threshold=0.3)
+    # the uint8 segmentation PredictionWriter stores: bit-exact (preds >= threshold) of the GPU's own probabilities
+    assert torch.equal(seg.cpu(), (probs.cpu() >= 0.3).to(torch.uint8))
     ref = F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), w, torch.tensor([b]), padding="same")[0, 0].clip(-5, 5)
     assert torch.allclose(logits.cpu(), ref, atol=1e-4, rtol=1e-4)
     assert torch.allclose(probs.cpu(), torch.sigmoid(ref), atol=1e-5)

@@ -120,3 +120,115 @@ def test_end_to_end_runner_configs_2_and_3(gpu, tmp_path):
     assert sorted(io.list_keys(pred)) == ["data", "mito", "mito_preds"]
     p = io.read_dataset(pred, "mito_preds")
     assert p.dtype == np.float32 and p.shape == (7, 64, 48) and 0.0066 <= p.min() and p.max() <= 0.9934
+
+
+def test_run_inference_against_oracle(gpu, tmp_path):
+    """``cryovit infer`` (run/infer_model.py:18-85 + PredictionWriter, callbacks.py:81-109) on files that hold
+    ``dino_features``: result files, key names, dtypes, and the uint8 segmentation against the fp32 oracle head.
+    bf16 activation storage moves logits by up to ~0.2 (tests/test_gpu_model.py), so disagreement is only allowed for
+    voxels whose oracle logit lies that close to the threshold."""
+    from typer.testing import CliRunner
+
+    from cryovit_amd import io
+    from cryovit_amd.cli import cli
+    from cryovit_amd.run.infer_model import run_inference
+    from cryovit_amd.types import ModelType
+    from cryovit_amd.utils import save_model_from_weights
+    from oracle import head as oh
+
+    ref = oh.CryoVITHead()
+    oh.rescaled_init_(ref, seed=5)
+    torch.save(ref.state_dict(), tmp_path / "weights.pt")
+    save_model_from_weights("demo", "mito", ModelType.CRYOVIT, tmp_path / "weights.pt", tmp_path / "demo.model")
+    rng = np.random.default_rng(9)
+    files, feats_all, vols = [], [], []
+    (tmp_path / "in").mkdir()
+    for i, D in enumerate((6, 9)):
+        vol = rng.integers(0, 256, size=(D, 48, 32), dtype=np.uint8)
+        feats = rng.standard_normal((1536, D, 3, 2)).astype(np.float16)
+        with io.FileWriter(tmp_path / "in" / f"tomo{i}.hdf") as f:
+            f.create_dataset("data", vol, compression="gzip")
+            f.create_dataset("dino_features", feats)
+        files.append(tmp_path / "in" / f"tomo{i}.hdf")
+        feats_all.append(feats)
+        vols.append(vol)
+    thr = 0.4
+    paths = run_inference(files, tmp_path / "demo.model", tmp_path / "out", threshold=thr)
+    assert paths == [tmp_path / "out" / "tomo0.hdf", tmp_path / "out" / "tomo1.hdf"]
+    logit_thr = float(np.log(thr / (1 - thr)))
+    for path, feats, vol in zip(paths, feats_all, vols):
+        assert sorted(io.list_keys(path)) == ["data", "mito_preds"]
+        data = io.read_dataset(path, "data")
+        assert data.dtype == np.float32 and np.array_equal(data, vol.astype(np.float32) / 255.0)
+        seg = io.read_dataset(path, "mito_preds")
+        assert seg.dtype == np.uint8 and seg.shape == vol.shape and set(np.unique(seg)) <= {0, 1}
+        with torch.no_grad():
+            logits = ref.forward_volume(torch.from_numpy(feats).float()[None])[0, 0].numpy()
+        want = (1.0 / (1.0 + np.exp(-logits)) >= thr).astype(np.uint8)
+        bad = seg != want
+        assert bad.mean() <= 0.05 and np.all(np.abs(logits[bad] - logit_thr) < 0.25), (bad.mean(), np.abs(logits[bad] - logit_thr).max())
+        assert 0.02 < seg.mean() < 0.98  # the synthetic head produces both classes
+    # the same through the command line (cli/infer_cli.py): folder argument, --model, --result-folder, --threshold
+    res = CliRunner().invoke(cli, ["infer", str(tmp_path / "in"), "--model", str(tmp_path / "demo.model"), "--result-folder",
+                                   str(tmp_path / "out_cli"), "--threshold", str(thr)])
+    assert res.exit_code == 0, res.output
+    for p in paths:
+        assert np.array_equal(io.read_dataset(tmp_path / "out_cli" / p.name, "mito_preds"), io.read_dataset(p, "mito_preds"))
+    res = CliRunner().invoke(cli, ["infer", str(tmp_path / "in"), "--model", str(tmp_path / "weights.pt")])
+    assert res.exit_code != 0  # "Model path does not exist or is not a .model file."
+
+
+def test_features_cli_then_infer_and_on_the_fly_encoder(gpu, tmp_path):
+    """``cryovit features`` (run_dino, run/dino_features.py:211-299) on an .mrc and an .hdf tomogram, then ``infer`` on the
+    produced files; and the build's shortcut -- ``run_inference(..., encoder=)`` on the raw files -- must give the same
+    segmentation up to the fp16-file vs bf16-in-HBM hand-over of the features."""
+    import struct
+
+    from typer.testing import CliRunner
+
+    import bench
+    from cryovit_amd import io
+    from cryovit_amd.cli import cli
+    from cryovit_amd.models import CryoVIT, load_encoder
+    from cryovit_amd.run.infer_model import run_inference
+    from cryovit_amd.utils import save_model
+
+    rng = np.random.default_rng(21)
+    (tmp_path / "raw").mkdir()
+    vol_a = rng.integers(0, 256, size=(5, 64, 48), dtype=np.uint8)
+    with io.FileWriter(tmp_path / "raw" / "a.hdf") as f:
+        f.create_dataset("data", vol_a, compression="gzip")
+        f.create_dataset("mito", rng.integers(-1, 2, size=vol_a.shape).astype(np.int8))
+    vol_b = rng.random((4, 64, 48)).astype(np.float32)
+    hdr = bytearray(1024)
+    hdr[0:16] = struct.pack("<4i", 48, 64, 4, 2)
+    hdr[208:216] = b"MAP " + bytes([0x44, 0x44, 0, 0])
+    (tmp_path / "raw" / "b.mrc").write_bytes(bytes(hdr) + vol_b.tobytes())
+    res = CliRunner().invoke(cli, ["features", str(tmp_path / "raw"), str(tmp_path / "feat"), "--batch-size", "3", "--synthetic-seed", "2"])
+    assert res.exit_code == 0, res.output
+    fa, fb = tmp_path / "feat" / "a.hdf", tmp_path / "feat" / "b.hdf"
+    assert sorted(io.list_keys(fa)) == ["data", "dino_features"]  # FileDataset hands only `data` to _save_data (file_dataset.py:96)
+    assert sorted(io.list_keys(fb)) == ["data", "dino_features"]
+    feats_b = io.read_dataset(fb, "dino_features")
+    assert feats_b.dtype == np.float16 and feats_b.shape == (1536, 4, 4, 3)
+    assert np.array_equal(io.read_dataset(fb, "data"), vol_b)  # float MRC data passes through un-normalised (utils.py:216-219)
+    enc = load_encoder("dinov2_vitg14_reg", synthetic_seed=2, device=gpu)
+    from cryovit_amd.run.dino_features import _dino_features
+
+    direct = _dino_features(torch.from_numpy(vol_a.astype(np.float32) / 255.0), enc, 5)
+    assert np.array_equal(io.read_dataset(fa, "dino_features"), direct)  # slice batching (3 vs 5) does not change features
+    model = CryoVIT(device=gpu)
+    model.load_state_dict({k: v.cpu() for k, v in bench.synthetic_head_state_dict(5, gpu).items()})
+    save_model("e2e", "mito", model, {"_target_": "cryovit_amd.models.CryoVIT", "name": "CryoVIT", "input_key": "dino_features"},
+               tmp_path / "e2e.model")
+    from_files = run_inference([fa, fb], tmp_path / "e2e.model", tmp_path / "seg_files")
+    on_the_fly = run_inference([tmp_path / "raw" / "a.hdf", tmp_path / "raw" / "b.mrc"], tmp_path / "e2e.model", tmp_path / "seg_raw",
+                               encoder=enc, batch_size=3)
+    assert [p.name for p in on_the_fly] == ["a.hdf", "b.hdf"]
+    for p, q in zip(from_files, on_the_fly):
+        s0, s1 = io.read_dataset(p, "mito_preds"), io.read_dataset(q, "mito_preds")
+        assert s0.shape == s1.shape and (s0 != s1).mean() <= 0.01, (s0 != s1).mean()
+        assert np.array_equal(io.read_dataset(p, "data"), io.read_dataset(q, "data"))
+    # without an encoder a file lacking dino_features fails like the reference: KeyError from the HDF5 lookup
+    with pytest.raises(KeyError):
+        run_inference([tmp_path / "raw" / "a.hdf"], tmp_path / "e2e.model", tmp_path / "seg_fail")
