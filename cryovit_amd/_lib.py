@@ -77,6 +77,12 @@ SIGNATURES = {
     "cvx_groupnorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
     "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_int, c_int, c_int, c_void_p]),
+    "cvx_sam_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),
+    "cvx_window_attention_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int,
+                                          c_int, c_int, c_int, c_void_p]),
+    "cvx_pool2x2": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
+    "cvx_cast_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
+    "cvx_fpn_level_out": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cvx_dice_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
     "cvx_vit_encode": (c_int, [C.POINTER(VitDesc), C.POINTER(VitWs), c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),

@@ -1,0 +1,350 @@
+// Kernels of the alternate encoder (SAM2.1 Hiera image encoder + FPN neck, BASELINE configs[4]) that the GEMM / LayerNorm
+// kernels of the ViT path do not already cover:
+//   k_sam_patches     bilinear resize to the encoder's image size + 7x7/stride-4/pad-3 patch gather -> bf16 GEMM operand
+//   k_win_attention   windowed / global multi-head attention on a token grid, head dims 56..96 (72 for Hiera-L), with the
+//                     queries optionally living on a 2x2-pooled grid (stage transitions)
+//   k_pool2x2         2x2 max pool over the token grid (fp32 residual shortcut, bf16 queries)
+//   k_cast_bf16       fp32 residual stream -> bf16 GEMM operand (FPN lateral convs)
+//   k_fpn_out         lateral (+ nearest-upsampled coarser level) -> float16 [D][C][h][w]
+// Activations are channels-last rows: row = (slice * G + y) * G + x.
+#include "common.h"
+#include "../../include/cryovit_hip.h"
+#include "host_util.h"
+
+namespace cvx {
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------
+// Patch gather.  out[(d*G + py)*G + px][c*49 + ky*7 + kx] = img(d, c, 4*py + ky - 3, 4*px + kx - 3)  (0 outside),
+// img = the [S][S] bilinear resample (align_corners = False, as F.interpolate(..., "trilinear") with an unchanged channel
+// extent does: src = max(0, (dst + 0.5) * H/S - 0.5)) of the source slice; identity when H == W == S.
+// mode 0: src uint8 [D][H][W] scaled by 1/255, 3 equal channels; 1: float [D][H][W], 3 equal channels; 2: float [D][3][H][W].
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float src_px(const void* __restrict__ src, int mode, long plane, int H, int W, int y, int x) {
+    const long i = plane * H * W + (long)y * W + x;
+    return mode == 0 ? (float)((const uint8_t*)src)[i] * (1.0f / 255.0f) : ((const float*)src)[i];
+}
+
+__global__ __launch_bounds__(256) void k_sam_patches(const void* __restrict__ src, int mode, int D, int H, int W, int S,
+                                                     uint16_t* __restrict__ out, int ldo) {
+    const int G = S / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)D * G * G * 160;  // 147 taps rounded up to a multiple of 32 lanes' worth
+    if (idx >= total) return;
+    const int k = (int)(idx % 160);
+    const long row = idx / 160;
+    if (k >= 147) return;
+    const int px = (int)(row % G), py = (int)((row / G) % G), d = (int)(row / ((long)G * G));
+    const int c = k / 49, ky = (k % 49) / 7, kx = k % 7;
+    const int y = 4 * py + ky - 3, x = 4 * px + kx - 3;
+    float v = 0.f;
+    if ((unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S) {
+        const long plane = mode == 2 ? (long)d * 3 + c : d;
+        if (H == S && W == S) {
+            v = src_px(src, mode, plane, H, W, y, x);
+        } else {
+            const float fy = fmaxf(((float)y + 0.5f) * ((float)H / (float)S) - 0.5f, 0.f);
+            const float fx = fmaxf(((float)x + 0.5f) * ((float)W / (float)S) - 0.5f, 0.f);
+            const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+            const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float a = src_px(src, mode, plane, H, W, y0, x0), b = src_px(src, mode, plane, H, W, y0, x1);
+            const float e = src_px(src, mode, plane, H, W, y1, x0), f = src_px(src, mode, plane, H, W, y1, x1);
+            v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * e + lx * f);
+        }
+    }
+    out[row * ldo + k] = f2bf(v);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Windowed attention.  One workgroup = one (slice, window, head, tile of 64 queries); wave w owns queries 16w..16w+15.
+// Swapped products on v_mfma_f32_16x16x16_bf16 (A rows x B columns):
+//   S^T[key][q] = K[key][:] . Q[q][:]     A = K rows from LDS (ds_read_b64), B = Q (registers)
+//   O^T[d][q]  += V^T[d][key] P^T[key][q]  A = V^T via ds_read_b64_tr_b16 (V stays row-major in LDS), B = P^T
+// The accumulator layout of S^T (lane: q = lane%16, keys 4g..4g+3) IS the B-operand layout of P^T: probabilities go
+// from the softmax to the second product without leaving the lane.  Online softmax over key tiles of 64.
+// ---------------------------------------------------------------------------------------------------
+template <int DSTEPS>
+__global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restrict__ q, long ldq, const uint16_t* __restrict__ k,
+                                                       const uint16_t* __restrict__ v, long ldkv, uint16_t* __restrict__ out,
+                                                       long ldo, int hd, int heads, int G, int ws, int Gq, int wsq,
+                                                       float scale_log2e) {
+    constexpr int LDR = 16 * DSTEPS + 8;  // LDS row stride (elements): 16-lane row reads land on distinct bank pairs
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[64 * LDR];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[64 * LDR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int head = blockIdx.y % heads, win = blockIdx.y / heads;
+    const int nwx = G / ws, wy = win / nwx, wx = win % nwx;
+    const long d = blockIdx.z;
+    const int nq = wsq * wsq, nk = ws * ws;
+    const int nthreads = blockDim.x;
+
+    // zero the pad columns [hd, 16*DSTEPS) of both tiles once: staging never touches them
+    for (int i = tid; i < 64 * (16 * DSTEPS - hd); i += nthreads) {
+        const int r = i / (16 * DSTEPS - hd), c = hd + i % (16 * DSTEPS - hd);
+        Ks[r * LDR + c] = 0;
+        Vs[r * LDR + c] = 0;
+    }
+
+    // this lane's query (B operand: column q = li, k = 16s + 4g .. +3)
+    const int ql = blockIdx.x * 64 + wave * 16 + li;
+    const bool q_ok = ql < nq;
+    const int qc = q_ok ? ql : 0;
+    const long qrow = d * Gq * Gq + (long)(wy * wsq + qc / wsq) * Gq + wx * wsq + qc % wsq;
+    v4s qf[DSTEPS];
+#pragma unroll
+    for (int s = 0; s < DSTEPS; ++s) {
+        const int c = 16 * s + 4 * g;
+        if (c < hd) qf[s] = *(const v4s*)(q + qrow * ldq + (long)head * hd + c);
+        else qf[s] = v4s{0, 0, 0, 0};
+    }
+
+    f32x4 o[DSTEPS];
+#pragma unroll
+    for (int t = 0; t < DSTEPS; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+
+    const int chunks = hd >> 2;  // 8-byte pieces per row
+    for (int k0 = 0; k0 < nk; k0 += 64) {
+        const int nkt = min(64, nk - k0), nsub = nkt >> 4;
+        __syncthreads();  // previous tile fully consumed (also orders the pad zeroing before the first reads)
+        for (int i = tid; i < nkt * chunks; i += nthreads) {
+            const int r = i / chunks, c = (i % chunks) * 4;
+            const int kl = k0 + r;
+            const long krow = d * G * G + (long)(wy * ws + kl / ws) * G + wx * ws + kl % ws;
+            *(uint2*)(Ks + r * LDR + c) = *(const uint2*)(k + krow * ldkv + (long)head * hd + c);
+            *(uint2*)(Vs + r * LDR + c) = *(const uint2*)(v + krow * ldkv + (long)head * hd + c);
+        }
+        __syncthreads();
+
+        f32x4 sacc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < nsub) {
+#pragma unroll
+                for (int s = 0; s < DSTEPS; ++s) {
+                    const v4s kf = *(const v4s*)(Ks + (16 * j + li) * LDR + 16 * s + 4 * g);
+                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf, qf[s], sacc[j], 0, 0, 0);
+                }
+            }
+        }
+        // online softmax for query li: this lane holds keys 16j + 4g + i; the other keys sit in lanes li + 16, 32, 48
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nsub) mx = fmaxf(mx, fmaxf(fmaxf(sacc[j][0], sacc[j][1]), fmaxf(sacc[j][2], sacc[j][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx * scale_log2e);
+        const float alpha = exp2f(m - m_new);
+        float ps = 0.f;
+        v4s pf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < nsub) {
+                float p[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    p[i] = exp2f(fmaf(sacc[j][i], scale_log2e, -m_new));
+                    ps += p[i];
+                }
+                const uint32_t w0 = pack2bf(p[0], p[1]), w1 = pack2bf(p[2], p[3]);
+                pf[j] = v4s{(short)(w0 & 0xffff), (short)(w0 >> 16), (short)(w1 & 0xffff), (short)(w1 >> 16)};
+            } else {
+                pf[j] = v4s{0, 0, 0, 0};
+            }
+        }
+        ps += __shfl_xor(ps, 16, 64);
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+        // V^T fragments: block of keys 16j+4g .. +3 x dims 16t .. 16t+15; lane 4r+p of a 16-lane group supplies row r, dims 4p..
+        const uint32_t vbase = (uint32_t)(size_t)(Vs + (4 * g + (li >> 2)) * LDR + 4 * (li & 3));
+#pragma unroll
+        for (int t = 0; t < DSTEPS; ++t) {
+            o[t] *= alpha;
+            v4s vf0, vf1, vf2, vf3;  // all four key sub-tiles in flight, one wait (rows past the tile are read but not used)
+            asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\t"
+                         "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+                         "ds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
+                         "ds_read_b64_tr_b16 %3, %4 offset:%8\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(vf0), "=&v"(vf1), "=&v"(vf2), "=&v"(vf3)
+                         : "v"(vbase), "n"(32 * t), "n"(32 * t + 32 * LDR), "n"(32 * t + 64 * LDR), "n"(32 * t + 96 * LDR)
+                         : "memory");
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf0, pf[0], o[t], 0, 0, 0);
+            if (nsub > 1) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf1, pf[1], o[t], 0, 0, 0);
+            if (nsub > 2) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf2, pf[2], o[t], 0, 0, 0);
+            if (nsub > 3) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf3, pf[3], o[t], 0, 0, 0);
+        }
+    }
+    if (!q_ok) return;
+    const float inv = 1.0f / l;
+    uint16_t* dst = out + qrow * ldo + (long)head * hd;
+#pragma unroll
+    for (int t = 0; t < DSTEPS; ++t) {
+        const int c = 16 * t + 4 * g;  // O^T rows (dims) 16t + 4g .. +3 of column q = li
+        if (c < hd) {
+            uint2 w;
+            w.x = pack2bf(o[t][0] * inv, o[t][1] * inv);
+            w.y = pack2bf(o[t][2] * inv, o[t][3] * inv);
+            *(uint2*)(dst + c) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 2x2 max pool over the token grid: in rows (d, y, x) on a G x G grid -> out rows on (G/2) x (G/2); C channels from column 0.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool2x2_f32(const float* __restrict__ in, long ldi, float* __restrict__ out, long ldo,
+                                                     int D, int G, int C) {
+    const int Go = G / 2, c4 = C / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)D * Go * Go * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    const long ro = idx / c4;
+    const int x = (int)(ro % Go), y = (int)((ro / Go) % Go);
+    const long d = ro / ((long)Go * Go);
+    const float* p = in + ((d * G + 2 * y) * G + 2 * x) * ldi + c;
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + ldi), e = *(const float4*)(p + (long)G * ldi),
+                 f = *(const float4*)(p + (long)G * ldi + ldi);
+    float4 r;
+    r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(e.x, f.x)); r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(e.y, f.y));
+    r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(e.z, f.z)); r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(e.w, f.w));
+    *(float4*)(out + ro * ldo + c) = r;
+}
+
+__device__ __forceinline__ uint32_t bfmax2(uint32_t a, uint32_t b) { return pack2bf(fmaxf(bflo(a), bflo(b)), fmaxf(bfhi(a), bfhi(b))); }
+
+__global__ __launch_bounds__(256) void k_pool2x2_bf16(const uint16_t* __restrict__ in, long ldi, uint16_t* __restrict__ out,
+                                                      long ldo, int D, int G, int C) {
+    const int Go = G / 2, c4 = C / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)D * Go * Go * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    const long ro = idx / c4;
+    const int x = (int)(ro % Go), y = (int)((ro / Go) % Go);
+    const long d = ro / ((long)Go * Go);
+    const uint16_t* p = in + ((d * G + 2 * y) * G + 2 * x) * ldi + c;
+    const uint2 a = *(const uint2*)p, b = *(const uint2*)(p + ldi), e = *(const uint2*)(p + (long)G * ldi),
+                f = *(const uint2*)(p + (long)G * ldi + ldi);
+    uint2 r;
+    r.x = bfmax2(bfmax2(a.x, b.x), bfmax2(e.x, f.x));
+    r.y = bfmax2(bfmax2(a.y, b.y), bfmax2(e.y, f.y));
+    *(uint2*)(out + ro * ldo + c) = r;
+}
+
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ in, long ldi, uint16_t* __restrict__ out, long ldo,
+                                                   long rows, int C) {
+    const int c4 = C / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    const long r = idx / c4;
+    const float4 a = *(const float4*)(in + r * ldi + c);
+    uint2 w;
+    w.x = pack2bf(a.x, a.y);
+    w.y = pack2bf(a.z, a.w);
+    *(uint2*)(out + r * ldo + c) = w;
+}
+
+// FPN level output: out[d][c][y][x] (float16) = lat[(d*g + y)*g + x][c] (+ coarse[(d*g/2 + y/2)*g/2 + x/2][c]), 64x64 tiles
+__global__ __launch_bounds__(256) void k_fpn_out(const float* __restrict__ lat, const float* __restrict__ coarse, int C, int g,
+                                                 _Float16* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int hw = g * g;
+    const long d = blockIdx.z;
+    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int t = t0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (t < hw && c < C) {
+            v = lat[(d * hw + t) * C + c];
+            if (coarse) {
+                const int y = t / g, x = t % g, gc = g / 2;
+                v += coarse[(d * gc * gc + (long)(y / 2) * gc + x / 2) * C + c];
+            }
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, t = t0 + tx;
+        if (c < C && t < hw) out[(d * C + c) * hw + t] = (_Float16)tile[tx][i];
+    }
+}
+
+}  // namespace cvx
+
+using namespace cvx;
+
+extern "C" int cvx_sam_patches(const void* src, int mode, int D, int H, int W, int S, void* out, long ldo, hipStream_t st) {
+    if (D <= 0) return 0;
+    if (mode < 0 || mode > 2 || S <= 0 || S % 4 || ldo < 147 || H <= 0 || W <= 0) return cvx_fail("sam_patches: bad arguments");
+    const long total = (long)D * (S / 4) * (S / 4) * 160;
+    hipLaunchKernelGGL(k_sam_patches, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, mode, D, H, W, S, (uint16_t*)out,
+                       (int)ldo);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_window_attention_bf16(const void* q, long ldq, const void* k, const void* v, long ldkv, void* out, long ldo,
+                                         int slices, int heads, int head_dim, int grid, int window, int q_grid, int q_window,
+                                         hipStream_t st) {
+    if (slices <= 0) return 0;
+    if (window <= 0 || grid % window || q_window <= 0 || q_grid % q_window || grid / window != q_grid / q_window)
+        return cvx_fail("window_attention: the key and query grids must hold the same whole number of windows");
+    const int nk = window * window, nq = q_window * q_window;
+    if (nk % 16) return cvx_fail("window_attention: keys per window must be a multiple of 16");
+    if (head_dim % 4 || head_dim < 8 || head_dim > 96 || ldq % 4 || ldkv % 4 || ldo % 4)
+        return cvx_fail("window_attention: head_dim must be a multiple of 4 in [8, 96], leading dimensions multiples of 4");
+    const int nwin = (grid / window) * (grid / window);
+    if ((long)nwin * heads > 65535 || slices > 65535) return cvx_fail("window_attention: grid too large");
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+    const dim3 blocks((nq + 63) / 64, nwin * heads, slices);
+    const dim3 threads(64 * (nq >= 64 ? 4 : (nq + 15) / 16));
+    const uint16_t *qq = (const uint16_t*)q, *kk = (const uint16_t*)k, *vv = (const uint16_t*)v;
+    if (head_dim <= 64)
+        hipLaunchKernelGGL(k_win_attention<4>, blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, head_dim, heads,
+                           grid, window, q_grid, q_window, scale_log2e);
+    else if (head_dim <= 80)
+        hipLaunchKernelGGL(k_win_attention<5>, blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, head_dim, heads,
+                           grid, window, q_grid, q_window, scale_log2e);
+    else
+        hipLaunchKernelGGL(k_win_attention<6>, blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, head_dim, heads,
+                           grid, window, q_grid, q_window, scale_log2e);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_pool2x2(const void* in, long ldi, void* out, long ldo, int slices, int grid, int C, int is_bf16,
+                           hipStream_t st) {
+    if (slices <= 0) return 0;
+    if (grid % 2 || C % 4 || ldi % 4 || ldo % 4) return cvx_fail("pool2x2: even grid, C and leading dimensions multiples of 4 required");
+    const long total = (long)slices * (grid / 2) * (grid / 2) * (C / 4);
+    const dim3 blocks((unsigned)((total + 255) / 256));
+    if (is_bf16)
+        hipLaunchKernelGGL(k_pool2x2_bf16, blocks, dim3(256), 0, st, (const uint16_t*)in, ldi, (uint16_t*)out, ldo, slices, grid, C);
+    else
+        hipLaunchKernelGGL(k_pool2x2_f32, blocks, dim3(256), 0, st, (const float*)in, ldi, (float*)out, ldo, slices, grid, C);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_cast_bf16(const float* in, long ldi, void* out, long ldo, long rows, int C, hipStream_t st) {
+    if (rows <= 0) return 0;
+    if (C % 4 || ldi % 4 || ldo % 4) return cvx_fail("cast_bf16: C and leading dimensions must be multiples of 4");
+    const long total = rows * (C / 4);
+    hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, ldi, (uint16_t*)out, ldo, rows, C);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_fpn_level_out(const float* lateral, const float* coarse, int slices, int C, int grid, void* out_f16,
+                                 hipStream_t st) {
+    if (slices <= 0) return 0;
+    if (coarse && grid % 2) return cvx_fail("fpn_level_out: top-down addition needs an even grid");
+    const dim3 blocks((grid * grid + 63) / 64, (C + 63) / 64, slices);
+    hipLaunchKernelGGL(k_fpn_out, blocks, dim3(256), 0, st, lateral, coarse, C, grid, (_Float16*)out_f16);
+    return cvx_check_launch();
+}

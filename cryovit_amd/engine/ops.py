@@ -150,3 +150,53 @@ def dice_sums(probs: torch.Tensor, labels: torch.Tensor, dice: torch.Tensor, thr
     _dev_check(probs, labels, dice)
     check(_lib.load().cvx_dice_sums(probs.data_ptr(), labels.data_ptr(), dice.data_ptr(), probs.numel(), thr, _stream()),
           "cvx_dice_sums")
+
+
+# ---- alternate encoder (SAM2 Hiera) ----
+
+
+def sam_patches(src: torch.Tensor, out: torch.Tensor, *, S: int) -> None:
+    """src: uint8 / float32 [D,H,W] (replicated to 3 channels) or float32 [D,3,H,W]; out bf16 [>= D*(S/4)^2, ld >= 147]."""
+    _dev_check(src, out)
+    if src.dim() == 4:
+        assert src.shape[1] == 3 and src.dtype == torch.float32
+        mode, (D, _, H, W) = 2, src.shape
+    else:
+        assert src.dtype in (torch.uint8, torch.float32)
+        mode, (D, H, W) = (0 if src.dtype == torch.uint8 else 1), src.shape
+    assert out.dtype == torch.bfloat16 and out.shape[0] >= D * (S // 4) ** 2
+    check(_lib.load().cvx_sam_patches(src.data_ptr(), mode, D, H, W, S, out.data_ptr(), out.stride(0), _stream()), "cvx_sam_patches")
+
+
+def window_attention(q: torch.Tensor, q_col: int, kv: torch.Tensor, k_col: int, v_col: int, out: torch.Tensor, *, slices: int,
+                     heads: int, head_dim: int, grid: int, window: int, q_grid: int, q_window: int) -> None:
+    """q / kv: bf16 row buffers; the q, k, v blocks start at the given columns (qkv GEMM output: 0, C, 2C)."""
+    _dev_check(q, kv, out)
+    assert q.dtype == kv.dtype == out.dtype == torch.bfloat16
+    assert q.shape[0] >= slices * q_grid * q_grid and kv.shape[0] >= slices * grid * grid and out.shape[0] >= slices * q_grid * q_grid
+    assert q_col + heads * head_dim <= q.shape[1] and max(k_col, v_col) + heads * head_dim <= kv.shape[1]
+    assert heads * head_dim <= out.shape[1]
+    check(_lib.load().cvx_window_attention_bf16(q.data_ptr() + 2 * q_col, q.stride(0), kv.data_ptr() + 2 * k_col,
+                                                kv.data_ptr() + 2 * v_col, kv.stride(0), out.data_ptr(), out.stride(0), slices, heads,
+                                                head_dim, grid, window, q_grid, q_window, _stream()), "cvx_window_attention_bf16")
+
+
+def pool2x2(x: torch.Tensor, out: torch.Tensor, *, slices: int, grid: int, C: int) -> None:
+    _dev_check(x, out)
+    assert x.dtype == out.dtype and x.dtype in (torch.float32, torch.bfloat16)
+    assert x.shape[0] >= slices * grid * grid and out.shape[0] >= slices * (grid // 2) ** 2 and C <= min(x.shape[1], out.shape[1])
+    check(_lib.load().cvx_pool2x2(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), slices, grid, C,
+                                  int(x.dtype == torch.bfloat16), _stream()), "cvx_pool2x2")
+
+
+def cast_bf16(x: torch.Tensor, out: torch.Tensor, *, rows: int, C: int) -> None:
+    _dev_check(x, out)
+    assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and min(x.shape[0], out.shape[0]) >= rows
+    check(_lib.load().cvx_cast_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, C, _stream()), "cvx_cast_bf16")
+
+
+def fpn_level_out(lateral: torch.Tensor, coarse, out: torch.Tensor, *, slices: int, C: int, grid: int) -> None:
+    _dev_check(lateral, coarse, out)
+    assert lateral.dtype == torch.float32 and lateral.shape[1] == C and out.dtype == torch.float16
+    assert out.numel() == slices * C * grid * grid and lateral.shape[0] >= slices * grid * grid
+    check(_lib.load().cvx_fpn_level_out(lateral.data_ptr(), _p(coarse), slices, C, grid, out.data_ptr(), _stream()), "cvx_fpn_level_out")

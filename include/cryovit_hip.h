@@ -162,6 +162,42 @@ int cvx_conv3_out_fused(const void* in, const float* w, float bias, float* logit
 int cvx_dice_sums(const float* probs, const int8_t* labels, float* dice, long n, float thr, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Alternate encoder: SAM2.1 Hiera image encoder + FPN neck (BASELINE configs[4]).  These entry points, together with
+ * cvx_gemm_bf16 (qkv / proj / MLP / patch-embed / lateral convs) and cvx_layernorm_bf16, replace
+ * `self.model.image_encoder(flat_data)` and the resize in front of it -- SAM2.forward_features,
+ * src/cryovit/models/sam2.py:190-209 -- whose outputs _sam_features stores as float16
+ * (src/cryovit/run/dino_features.py:67-106).  Token rows are channels-last: row = (slice * G + y) * G + x.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Resize to S x S (bilinear, align_corners = False: the in-plane part of the reference's trilinear F.interpolate,
+ * sam2.py:196-203; identity when H == W == S) and gather the 7x7 / stride 4 / pad 3 patches of the patch-embedding
+ * conv as a bf16 GEMM operand out[slices*(S/4)^2][ldo], column c*49 + ky*7 + kx (zero outside the image).
+ * mode 0: src uint8 [D][H][W] scaled by 1/255 and replicated to 3 channels (vit_dataset.py:86-88,136-137);
+ * mode 1: float [D][H][W] replicated; mode 2: float [D][3][H][W]. */
+int cvx_sam_patches(const void* src, int mode, int slices, int H, int W, int S, void* out, long ldo, hipStream_t stream);
+
+/* Multi-head attention inside windows of a token grid (Hiera's MultiScaleAttention after window_partition):
+ * keys/values k, v: bf16 rows on a grid x grid token grid (leading dimension ldkv, head h at column h*head_dim),
+ * windows of window x window tokens (window == grid: global attention); queries q on a q_grid x q_grid grid with
+ * q_window x q_window windows -- the same grid, or the 2x2-pooled one of a stage transition.  out rows follow the query
+ * grid.  softmax(q k^T / sqrt(head_dim)) v per (slice, window, head).  window^2 % 16 == 0, head_dim % 4 == 0, <= 96. */
+int cvx_window_attention_bf16(const void* q, long ldq, const void* k, const void* v, long ldkv, void* out, long ldo,
+                              int slices, int heads, int head_dim, int grid, int window, int q_grid, int q_window,
+                              hipStream_t stream);
+
+/* 2x2 max pool over the token grid (Hiera's do_pool): rows on grid x grid -> rows on grid/2 x grid/2, C channels;
+ * fp32 (is_bf16 = 0: the residual shortcut) or bf16 (the queries). */
+int cvx_pool2x2(const void* in, long ldi, void* out, long ldo, int slices, int grid, int C, int is_bf16, hipStream_t stream);
+
+/* fp32 rows -> bf16 rows (residual stream -> GEMM operand of the FPN lateral convs). */
+int cvx_cast_bf16(const float* in, long ldi, void* out, long ldo, long rows, int C, hipStream_t stream);
+
+/* One FPN level: out_f16[slice][c][y][x] = lateral[(slice*grid + y)*grid + x][c] (+ coarse[(slice*grid/2 + y/2)*grid/2
+ * + x/2][c] when coarse != NULL: the nearest-upsampled top-down term), fp32 in, float16 out. */
+int cvx_fpn_level_out(const float* lateral, const float* coarse, int slices, int C, int grid, void* out_f16,
+                      hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * The whole DINOv2-with-registers encoder for one slice batch as ONE call: token init + patch-embed
  * GEMM, `depth` x { LN, QK GEMM, V^T GEMM, attention, proj GEMM (LayerScale+residual), LN, FFN-in GEMM (SwiGLU gate or
  * GELU), FFN-out GEMM (LayerScale+residual) }, final LN + feature layouts.  Replaces the hub model's forward_features

@@ -1,0 +1,153 @@
+"""Alternate encoder (SAM2.1 Hiera image encoder + FPN neck, BASELINE configs[4]) on the GPU against the CPU oracle
+``oracle/sam2_hiera.py`` (restatement of the sam2 package's ImageEncoder, cross-checked against the HF port in
+``tests/test_cpu_oracle.py``).  Kernel-level cases first, then the whole encoder on a reduced-width Hiera with the same
+head dim (72) and the same structural cases as Hiera-L."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _rows_from_grid(t):  # [D,G,G,C] -> rows
+    return t.reshape(-1, t.shape[-1])
+
+
+@pytest.mark.parametrize("G,ws,heads,hd,pooled", [(16, 8, 2, 72, False), (16, 8, 2, 72, True), (32, 32, 1, 72, False), (8, 4, 3, 72, False),
+                                                   (8, 4, 2, 72, True), (16, 16, 2, 64, False), (16, 8, 1, 96, True), (32, 16, 2, 56, False)])
+def test_window_attention(gpu, G, ws, heads, hd, pooled):
+    """softmax(q k^T / sqrt(hd)) v inside windows; pooled: queries are the 2x2 max pool of q (Hiera stage transition)."""
+    from cryovit_amd.engine import ops
+
+    D, C = 3, heads * hd
+    g = torch.Generator().manual_seed(G * 100 + ws + hd)
+    qkv = bf(torch.randn(D, G, G, 3 * C, generator=g) * 1.5)
+    rows = D * G * G
+    buf = torch.zeros(ops.alloc_rows(rows), 3 * C, dtype=torch.bfloat16, device=gpu)
+    buf[:rows] = _rows_from_grid(qkv).to(gpu)
+    Gq, wsq = (G // 2, ws // 2) if pooled else (G, ws)
+    out = torch.zeros(ops.alloc_rows(D * Gq * Gq), C + 24, dtype=torch.bfloat16, device=gpu)
+    if pooled:
+        qp = torch.zeros(ops.alloc_rows(D * Gq * Gq), C, dtype=torch.bfloat16, device=gpu)
+        ops.pool2x2(buf, qp, slices=D, grid=G, C=C)
+        qref = F.max_pool2d(qkv[..., :C].float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        assert torch.equal(qp[: D * Gq * Gq].float().cpu(), _rows_from_grid(qref))  # max of bf16 values: exact
+        ops.window_attention(qp, 0, buf, C, 2 * C, out, slices=D, heads=heads, head_dim=hd, grid=G, window=ws, q_grid=Gq, q_window=wsq)
+    else:
+        qref = qkv[..., :C].float()
+        ops.window_attention(buf, 0, buf, C, 2 * C, out, slices=D, heads=heads, head_dim=hd, grid=G, window=ws, q_grid=G, q_window=ws)
+
+    def windows(t, w):  # [D,g,g,c] -> [D*nw, w*w, heads, hd]
+        Dn, gg, _, c = t.shape
+        t = t.reshape(Dn, gg // w, w, gg // w, w, c).permute(0, 1, 3, 2, 4, 5)
+        return t.reshape(-1, w * w, heads, hd)
+
+    q = windows(qref, wsq).transpose(1, 2)
+    k = windows(qkv[..., C : 2 * C].float(), ws).transpose(1, 2)
+    v = windows(qkv[..., 2 * C :].float(), ws).transpose(1, 2)
+    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(D, Gq // wsq, Gq // wsq, wsq, wsq, C)
+    ref = o.permute(0, 1, 3, 2, 4, 5).reshape(D * Gq * Gq, C)
+    got = out[: D * Gq * Gq, :C].float().cpu()
+    err = (got - ref).abs()
+    assert err.max() <= 3e-2 and err.mean() <= 3e-3, (float(err.max()), float(err.mean()))
+    assert torch.all(out[:, C:] == 0) and torch.all(out[D * Gq * Gq :] == 0)  # nothing outside the valid block is written
+
+
+def test_pool_cast_fpn(gpu):
+    from cryovit_amd.engine import ops
+
+    D, G, C = 2, 12, 40
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(D, G, G, C, generator=g)
+    xin = torch.zeros(ops.alloc_rows(D * G * G), C + 8, device=gpu)
+    xin[: D * G * G, :C] = _rows_from_grid(x).to(gpu)
+    out = torch.zeros(ops.alloc_rows(D * 36), C, device=gpu)
+    ops.pool2x2(xin, out, slices=D, grid=G, C=C)
+    ref = F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(out[: D * 36].cpu(), _rows_from_grid(ref))
+    cb = torch.zeros(ops.alloc_rows(D * G * G), 64, dtype=torch.bfloat16, device=gpu)
+    ops.cast_bf16(xin, cb, rows=D * G * G, C=C)
+    assert torch.equal(cb[: D * G * G, :C].cpu(), bf(_rows_from_grid(x))) and torch.all(cb[:, C:] == 0)
+    # FPN level: lateral + nearest-upsampled coarser level -> float16 [D,C,g,g]
+    Cf = 72
+    lat = torch.randn(D * G * G, Cf, generator=g)
+    coarse = torch.randn(D * 36, Cf, generator=g)
+    o16 = torch.zeros(D, Cf, G, G, dtype=torch.float16, device=gpu)
+    ops.fpn_level_out(lat.to(gpu), coarse.to(gpu), o16, slices=D, C=Cf, grid=G)
+    lat_i = lat.reshape(D, G, G, Cf).permute(0, 3, 1, 2)
+    co_i = coarse.reshape(D, 6, 6, Cf).permute(0, 3, 1, 2)
+    want = (lat_i + F.interpolate(co_i, scale_factor=2.0, mode="nearest")).half()
+    assert torch.equal(o16.cpu(), want)
+    ops.fpn_level_out(lat.to(gpu), None, o16, slices=D, C=Cf, grid=G)
+    assert torch.equal(o16.cpu(), lat_i.half())
+
+
+@pytest.mark.parametrize("H,W,dtype", [(64, 64, "u8"), (40, 56, "f32"), (100, 72, "u8"), (64, 64, "rgb")])
+def test_sam_patches(gpu, H, W, dtype):
+    """resize (sam2.py:196-203) + 7x7/4/3 patch gather == unfold of the oracle's resized image, to bf16 rounding."""
+    from cryovit_amd.engine import ops
+    from oracle import sam2_hiera as oh
+
+    S, D = 64, 3
+    rng = np.random.default_rng(H + W)
+    if dtype == "u8":
+        vol = torch.from_numpy(rng.integers(0, 256, (D, H, W), dtype=np.uint8))
+        data = (vol.float() / 255.0)[None, :, None].repeat(1, 1, 3, 1, 1)
+    elif dtype == "f32":
+        vol = torch.from_numpy(rng.random((D, H, W), dtype=np.float32))
+        data = vol[None, :, None].repeat(1, 1, 3, 1, 1)
+    else:
+        vol = torch.from_numpy(rng.random((D, 3, H, W), dtype=np.float32))
+        data = vol[None]
+    img = oh.resize_input(data, S)  # [D,3,S,S]
+    ref = F.unfold(img, kernel_size=7, stride=4, padding=3).transpose(1, 2).reshape(D * 16 * 16, 147)
+    out = torch.zeros(ops.alloc_rows(D * 256), 192, dtype=torch.bfloat16, device=gpu)
+    ops.sam_patches(vol.to(gpu), out, S=S)
+    got = out[: D * 256, :147].float().cpu()
+    assert (got - ref).abs().max() <= 4e-3 + 1e-6  # bf16 rounding of values in [0,1]
+    assert torch.all(out[:, 147:] == 0)
+    if H == S and W == S:
+        assert torch.equal(out[: D * 256, :147].cpu(), bf(ref))  # no resize: bit-exact
+
+
+def _encoder_case(gpu, vol, cfg_name="test"):
+    from cryovit_amd.engine.hiera import HieraConfig, HieraEngine
+    from oracle import sam2_hiera as oh
+
+    ocfg = oh.HIERA_TEST
+    cfg = HieraConfig(ocfg.embed_dim, ocfg.num_heads, ocfg.stages, ocfg.global_att_blocks, ocfg.window_spec,
+                      image_size=ocfg.image_size)
+    assert cfg.block_plan() == ocfg.block_plan()
+    sd = oh.init_state_dict(ocfg, seed=3)
+    eng = HieraEngine(cfg, {"image_encoder." + k: v for k, v in sd.items()}, gpu)  # checkpoint-style prefix
+    D = vol.shape[0]
+    outs = [torch.zeros(D, cfg.d_model, g, g, dtype=torch.float16, device=gpu) for g in eng.grids[: eng.n_levels()]]
+    for d0 in range(0, D, 3):  # slice batches must not change the result
+        eng.encode(vol[d0 : d0 + 3].to(gpu), outs, d0)
+    data = (vol.float() / 255.0 if vol.dtype == torch.uint8 else vol.float())[None, :, None].repeat(1, 1, 3, 1, 1)
+    ref = oh.sam_features(ocfg, sd, data)
+    return eng, outs, ref
+
+
+@pytest.mark.parametrize("H", [128, 96])
+def test_hiera_encoder_vs_oracle(gpu, H):
+    """Whole image encoder (patch embed, 8 blocks incl. three q-pooled transitions and global blocks, 4-level neck with the
+    top-down path, scalp) vs the fp32 oracle; H = 96 exercises the bilinear resize to the encoder's 128x128."""
+    rng = np.random.default_rng(H)
+    vol = torch.from_numpy(rng.integers(0, 256, (4, H, H), dtype=np.uint8))
+    eng, outs, ref = _encoder_case(gpu, vol)
+    assert [tuple(o.shape) for o in outs] == [(4, 256, 32, 32), (4, 256, 16, 16), (4, 256, 8, 8)]
+    for lvl, (o, r) in enumerate(zip(outs, ref["backbone_fpn"])):
+        r = torch.from_numpy(r).float()
+        err = (o.float().cpu() - r).abs()
+        scale = float(r.abs().mean())
+        # bf16 GEMM operands / fp32 accumulation and residual stream: same class of tolerance as the ViT path
+        assert err.max() <= 0.15 * max(1.0, scale) and err.mean() <= 0.02 * max(1.0, scale), (lvl, float(err.max()), float(err.mean()), scale)
+    for lvl, r in enumerate(ref["vision_pos_enc"]):
+        assert torch.equal(eng.pos_enc(lvl), torch.from_numpy(r[0]))  # input independent: bit-exact fp16
