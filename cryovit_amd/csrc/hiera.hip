@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx * scale_log2e);
-        const float alpha = exp2f(m - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
         float ps = 0.f;
         v4s pf[4];
 #pragma unroll
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
                 float p[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    p[i] = exp2f(fmaf(sacc[j][i], scale_log2e, -m_new));
+                    p[i] = __builtin_amdgcn_exp2f(fmaf(sacc[j][i], scale_log2e, -m_new));
                     ps += p[i];
                 }
                 const uint32_t w0 = pack2bf(p[0], p[1]), w1 = pack2bf(p[2], p[3]);
@@ -162,23 +162,28 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
         l = l * alpha + ps;
         m = m_new;
         // V^T fragments: block of keys 16j+4g .. +3 x dims 16t .. 16t+15; lane 4r+p of a 16-lane group supplies row r, dims 4p..
+        // All 4*DSTEPS transposed reads are issued back to back and waited for once (rows past the tile are read, not used).
         const uint32_t vbase = (uint32_t)(size_t)(Vs + (4 * g + (li >> 2)) * LDR + 4 * (li & 3));
+        v4s vf[DSTEPS][4];
 #pragma unroll
-        for (int t = 0; t < DSTEPS; ++t) {
-            o[t] *= alpha;
-            v4s vf0, vf1, vf2, vf3;  // all four key sub-tiles in flight, one wait (rows past the tile are read but not used)
+        for (int t = 0; t < DSTEPS; ++t)
             asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%5\n\t"
                          "ds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
                          "ds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
-                         "ds_read_b64_tr_b16 %3, %4 offset:%8\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(vf0), "=&v"(vf1), "=&v"(vf2), "=&v"(vf3)
+                         "ds_read_b64_tr_b16 %3, %4 offset:%8"
+                         : "=&v"(vf[t][0]), "=&v"(vf[t][1]), "=&v"(vf[t][2]), "=&v"(vf[t][3])
                          : "v"(vbase), "n"(32 * t), "n"(32 * t + 32 * LDR), "n"(32 * t + 64 * LDR), "n"(32 * t + 96 * LDR)
                          : "memory");
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf0, pf[0], o[t], 0, 0, 0);
-            if (nsub > 1) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf1, pf[1], o[t], 0, 0, 0);
-            if (nsub > 2) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf2, pf[2], o[t], 0, 0, 0);
-            if (nsub > 3) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf3, pf[3], o[t], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < DSTEPS; ++t) {
+            // ties the fragments to the wait above: the MFMAs below consume the outputs of this (ordered) statement
+            asm volatile("" : "+v"(vf[t][0]), "+v"(vf[t][1]), "+v"(vf[t][2]), "+v"(vf[t][3]));
+            o[t] *= alpha;
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][0], pf[0], o[t], 0, 0, 0);
+            if (nsub > 1) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][1], pf[1], o[t], 0, 0, 0);
+            if (nsub > 2) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][2], pf[2], o[t], 0, 0, 0);
+            if (nsub > 3) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][3], pf[3], o[t], 0, 0, 0);
         }
     }
     if (!q_ok) return;

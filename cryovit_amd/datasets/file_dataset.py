@@ -27,8 +27,6 @@ class FileDataset(Dataset):
                  for_dino: bool = False, use_sam: bool = False) -> None:
         if train:
             raise NotImplementedError("training crops are out of scope of this build (SURVEY s.8f N4)")
-        if use_sam:
-            raise NotImplementedError("the SAM2 encoder path (configs[4], SURVEY s.8f N3) is not built yet")
         self.files = files
         self.input_key, self.label_key = input_key, label_key
         self.train, self.for_dino, self.use_sam = train, for_dino, use_sam

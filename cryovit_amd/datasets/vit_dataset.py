@@ -21,8 +21,8 @@ from cryovit_amd import io
 class VITDataset(Dataset):
     def __init__(self, data_root, use_sam: bool, records: list[str]) -> None:
         self.root = data_root if isinstance(data_root, Path) else Path(data_root)
-        if use_sam:
-            raise NotImplementedError("the SAM2 encoder path (configs[4], SURVEY s.8f N3) is not built yet")
+        # use_sam: the reference's _sam_transform (l.125-142) only adds a batch axis and replicates the slice to 3 channels;
+        # both happen inside the encoder's first kernel here (cvx_sam_patches), so the item is the same raw volume.
         self.use_sam = use_sam
         self.records = records
 

@@ -123,8 +123,12 @@ def sine_position_encoding(d_model: int, h: int, w: int, temperature: float = 10
     return torch.cat((py, px), dim=2).permute(2, 0, 1).contiguous()
 
 
-def _npad(n: int) -> int:
-    """Output-width padding: the widest GEMM tile whose padding waste stays below 15 %."""
+def _npad(n: int, k: int = 0) -> int:
+    """Output-width padding = GEMM tile choice.  The 256x256 pipeline (K >= 256) runs at about twice the rate of the
+    128-wide tile kernel, so it is worth up to a third of padded columns (N = 576 -> 768); otherwise the widest tile whose
+    padding stays below 15 %."""
+    if k >= 256 and round_up(n, 256) - n <= 0.34 * n:
+        return round_up(n, 256)
     for t in (256, 128):
         if round_up(n, t) - n <= 0.15 * n:
             return round_up(n, t)
@@ -167,7 +171,7 @@ class HieraEngine:
         def lin(wk, bk):
             w, b = g(wk), g(bk)
             w = w.reshape(w.shape[0], -1)
-            n_pad, k_pad = _npad(w.shape[0]), round_up(w.shape[1], 64)
+            n_pad, k_pad = _npad(w.shape[0], w.shape[1]), round_up(w.shape[1], 64)
             wp = torch.zeros(n_pad, k_pad, dtype=torch.bfloat16, device=dev)
             wp[: w.shape[0], : w.shape[1]] = w.to(dev).to(torch.bfloat16)
             bp = torch.zeros(n_pad, dtype=torch.float32, device=dev)
@@ -196,7 +200,7 @@ class HieraEngine:
             self.blocks.append(blk)
         n = len(cfg.stages) - 1
         self.neck = [lin(f"neck.convs.{n - s}.conv.weight", f"neck.convs.{n - s}.conv.bias") for s in range(n + 1)]  # by stage
-        self.ones = torch.ones(max(max(cfg.dims), cfg.d_model) + 256, dtype=torch.float32, device=dev)
+        self.ones = torch.ones(round_up(max(max(cfg.dims), cfg.d_model), 256) + 256, dtype=torch.float32, device=dev)
 
     # ---- workspaces ---------------------------------------------------------------------------------------------
     def _buf(self, name: str, rows: int, cols: int, dtype) -> torch.Tensor:

@@ -21,6 +21,7 @@ import torch
 from cryovit_amd import io
 from cryovit_amd.config import instantiate, samples, tomogram_exts
 from cryovit_amd.models.encoder import load_encoder
+from cryovit_amd.models.sam_encoder import load_sam_encoder
 from cryovit_amd.run.sharding import shard_records, world_info
 
 
@@ -46,18 +47,46 @@ def _dino_features(data: torch.Tensor, model, batch_size: int) -> np.ndarray:
     return np.concatenate(chunks, axis=1)
 
 
-def _save_data(data: dict[str, np.ndarray], features: np.ndarray, tomo_name: str, dst_dir: Path) -> None:
-    """``data`` (gzip), every other source leaf under ``labels/`` (gzip), ``dino_features`` uncompressed (l.119-153)."""
+@torch.inference_mode()
+def _sam_features(data: torch.Tensor, model, batch_size: int) -> dict[str, list[np.ndarray]]:
+    """SAM2 image-encoder features of one tomogram (mirror of l.67-106): every key of the encoder output except
+    ``vision_features`` as a list (fine -> coarse) of float16 arrays ``[D, 256, h_l, w_l]``.
+
+    ``data`` is the raw volume ``[D,H,W]`` (fused path) or the reference's ``[1,D,3,H,W]`` float tensor (protocol path
+    through ``model.forward_features``; ``len(data) == 1``, so the whole tomogram is one call like upstream)."""
+    if data.dim() == 3:
+        return model.features_from_raw(data, batch_size)
+    all_features: dict[str, list[np.ndarray]] = {}
+    for i in range(0, len(data), batch_size):
+        backbone = model.forward_features(data[i : i + batch_size])
+        for key, feats in backbone.items():
+            if key == "vision_features":
+                continue
+            arrs = [f.to("cpu").half().numpy() for f in feats]
+            all_features[key] = arrs if key not in all_features else [np.concatenate([a, b], axis=0) for a, b in zip(all_features[key], arrs)]
+    return all_features
+
+
+def _save_data(data: dict[str, np.ndarray], features, tomo_name: str, dst_dir: Path) -> None:
+    """``data`` (gzip), every other source leaf under ``labels/`` (gzip); DINO: ``dino_features`` uncompressed; SAM (dict of
+    lists): the source's ``dino_features`` kept (gzip) and ``sam_features/<key>/<level>`` uncompressed (l.119-153)."""
     dst_dir.mkdir(parents=True, exist_ok=True)
     with io.FileWriter(dst_dir / tomo_name) as fh:
         for key, arr in data.items():
             if key == "dino_features":
-                continue  # stale features of the source are dropped
+                continue  # stale features of the source are dropped (re-added below for the SAM case)
             if key == "data":
                 fh.create_dataset("data", arr, compression="gzip")
             else:
                 fh.create_dataset(f"labels/{key}", arr, compression="gzip")
-        fh.create_dataset("dino_features", features)
+        if isinstance(features, dict):
+            if "dino_features" in data:
+                fh.create_dataset("dino_features", data["dino_features"], compression="gzip")
+            for key, feats in features.items():
+                for i, feat in enumerate(feats):
+                    fh.create_dataset(f"sam_features/{key}/{i}", feat)
+        else:
+            fh.create_dataset("dino_features", features)
 
 
 def _list_records(tomo_dir: Path, csv_file: Path) -> list[str]:
@@ -77,9 +106,12 @@ def _process_sample(src_dir: Path, dst_dir: Path, csv_dir: Path, model, sample: 
     done = []
     # Three-stage host pipeline around the GPU (the reference runs these serially, SURVEY s.8a a3): a reader thread
     # decompresses tomogram i+1 while the GPU works on i, a writer thread gzips and writes i-1 (zlib drops the GIL).
+    feature_fn = _sam_features if use_sam else _dino_features
+
     def save(i, features):
         _save_data(io.read_all_flat(tomo_dir / mine[i]), features, mine[i], result_dir)
-        logging.info("[rank %d] %s/%s -> dino_features %s", rank, sample, mine[i], features.shape)
+        shapes = features.shape if not isinstance(features, dict) else {k: [f.shape for f in v] for k, v in features.items()}
+        logging.info("[rank %d] %s/%s -> %s %s", rank, sample, mine[i], "sam_features" if use_sam else "dino_features", shapes)
         return mine[i]
 
     with ThreadPoolExecutor(max_workers=1) as reader, ThreadPoolExecutor(max_workers=2) as writer:
@@ -88,7 +120,7 @@ def _process_sample(src_dir: Path, dst_dir: Path, csv_dir: Path, model, sample: 
         for i in range(len(dataset)):
             x = nxt.result()
             nxt = reader.submit(dataset.__getitem__, i + 1) if i + 1 < len(dataset) else None
-            features = _dino_features(x, model, batch_size)
+            features = feature_fn(x, model, batch_size)
             pending.append(writer.submit(save, i, features))
             while len(pending) > 2:  # bound the number of 400-MB feature arrays waiting to be written
                 done.append(pending.pop(0).result())
@@ -96,6 +128,16 @@ def _process_sample(src_dir: Path, dst_dir: Path, csv_dir: Path, model, sample: 
     if image_dir is not None:
         logging.warning("export_features=True: PCA colour maps are plotting (out of scope of this build) -- skipped")
     return done
+
+
+def _load_model(cfg, enc: dict, device: str):
+    """The frozen encoder: SAM2 image encoder for ``use_sam`` (l.325-331), else DINOv2 (l.332-336); weights from local files."""
+    if cfg.use_sam:
+        assert cfg.get("model") is not None, "SAM model configuration must be provided."
+        return load_sam_encoder(enc.get("name") or cfg.model.get("name", "SAM2"), model_dir=cfg.model_dir, checkpoint=enc.get("checkpoint"),
+                                synthetic_seed=enc.get("synthetic_seed"), device=device).cuda().eval()
+    return load_encoder(enc.get("name", "dinov2_vitg14_reg"), model_dir=cfg.model_dir, checkpoint=enc.get("checkpoint"),
+                        synthetic_seed=enc.get("synthetic_seed"), device=device).cuda().eval()
 
 
 def run_trainer(cfg) -> None:
@@ -107,15 +149,12 @@ def run_trainer(cfg) -> None:
     image_dir = exp_dir / "dino_images"
     sample = cfg.sample
     sample_names = [getattr(sample, "name", sample)] if sample is not None else [s for s in samples if (src_dir / s).exists()]
-    if cfg.use_sam:
-        raise NotImplementedError("use_sam=True (SAM2 Hiera-L features, BASELINE configs[4]) is a later row of SURVEY s.8f")
     enc = cfg.get("encoder", {}) or {}
     _, local_rank, _ = world_info()
     device = enc.get("device", "cuda:0")
     if world_info()[2] > 1:
         device = f"cuda:{local_rank}"
-    model = load_encoder(enc.get("name", "dinov2_vitg14_reg"), model_dir=cfg.model_dir, checkpoint=enc.get("checkpoint"),
-                         synthetic_seed=enc.get("synthetic_seed"), device=device).cuda().eval()
+    model = _load_model(cfg, enc, device)
     for sample_name in sample_names:
         _process_sample(src_dir, dst_dir, csv_dir, model, sample_name, cfg.datamodule, cfg.batch_size,
                         image_dir if cfg.export_features else None, cfg.use_sam)
@@ -132,15 +171,14 @@ def run_dino(train_data: list[Path], result_dir: Path, batch_size: int, use_sam:
     from cryovit_amd.config import compose
     from cryovit_amd.types import FileData
 
-    if use_sam:
-        raise NotImplementedError("use_sam=True (SAM2 Hiera-L features, BASELINE configs[4]) is a later row of SURVEY s.8f")
-    cfg = compose("dino_features", [f"batch_size={batch_size}", "sample=null", "export_features=False", "datamodule/dataset=file"])
+    cfg = compose("dino_features" if not use_sam else "sam_features",
+                  [f"batch_size={batch_size}", "sample=null", "export_features=False", "datamodule/dataset=file"])
     enc = dict(cfg.get("encoder", {}) or {})
     enc.update(encoder or {})
     rank, local_rank, world = world_info()
     device = f"cuda:{local_rank}" if world > 1 else enc.get("device", "cuda:0")
-    model = load_encoder(enc.get("name", "dinov2_vitg14_reg"), model_dir=cfg.model_dir, checkpoint=enc.get("checkpoint"),
-                         synthetic_seed=enc.get("synthetic_seed"), device=device).cuda().eval()
+    model = _load_model(cfg, enc, device)
+    feature_fn = _sam_features if use_sam else _dino_features
     assert len(train_data) > 0, "No valid tomogram files found in the specified training data path."
     files = [FileData(tomo_path=Path(f)) for f in train_data]
     dataset = instantiate(cfg.datamodule.dataset, input_key=None, label_key=None)(files, for_dino=True, use_sam=use_sam)
@@ -152,7 +190,7 @@ def run_dino(train_data: list[Path], result_dir: Path, batch_size: int, use_sam:
             pending = []
             for i in shard_records(files, rank, world):
                 x = dataset[i]
-                features = _dino_features(x.data, model, cfg.batch_size)
+                features = feature_fn(x.data, model, cfg.batch_size)
                 result_path = result_list[i].with_suffix(".hdf")
                 pending.append(writer.submit(_save_data, x.aux_data, features, result_path.name, result_path.parent))
                 while len(pending) > 2:

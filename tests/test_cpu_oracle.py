@@ -83,3 +83,44 @@ def test_e2e_fixture_is_nondegenerate(gold):
     g = gold("e2e_tiny.npz")
     fg = float((g["probs"] > 0.5).mean())
     assert 0.05 < fg < 0.95 and 0.0 < float(g["dice"]) < 1.0
+
+
+def test_sam2_hiera_oracle_matches_hf_port():
+    """The SAM2 image-encoder restatement (oracle/sam2_hiera.py; the sam2 package is absent) against the installed HF port
+    ``transformers.models.sam2`` with identical seeded weights: FPN features to fp32 round-off, position encodings exactly.
+    Also pins the block plan of Hiera-L (window lag, q-pool blocks, global blocks) to the HF config's per-block attributes."""
+    import torch
+
+    from oracle import sam2_hiera as oh
+
+    cfg = oh.HIERA_TEST
+    sd = oh.init_state_dict(cfg, seed=3)
+    img = torch.rand(2, 3, cfg.image_size, cfg.image_size, generator=torch.Generator().manual_seed(0))
+    errs = oh.hf_cross_check(cfg, sd, img)
+    assert max(v for k, v in errs.items() if k.startswith("fpn")) <= 5e-5, errs
+    assert max(v for k, v in errs.items() if k.startswith("pos")) == 0.0, errs
+    # resize convention of SAM2.forward_features: trilinear over (c,h,w) with c unchanged == bilinear in the plane
+    d = torch.rand(1, 2, 3, 40, 56, generator=torch.Generator().manual_seed(1))
+    r = oh.resize_input(d, 64)
+    assert r.shape == (2, 3, 64, 64)
+    assert torch.allclose(r, torch.nn.functional.interpolate(d[0], size=(64, 64), mode="bilinear", align_corners=False), atol=1e-6)
+    assert oh.resize_input(d[..., :40, :40], 40).shape == (2, 3, 40, 40)
+    # Hiera-L plan against the HF blocks built from the same hyper-parameters (structure only: meta device, no weights)
+    from transformers.models.sam2.configuration_sam2 import Sam2HieraDetConfig
+    from transformers.models.sam2.modeling_sam2 import Sam2MultiScaleBlock
+
+    L = oh.HIERA_L
+    hc = Sam2HieraDetConfig(hidden_size=L.embed_dim, num_attention_heads=L.num_heads, blocks_per_stage=list(L.stages),
+                            embed_dim_per_stage=list(L.dims), num_attention_heads_per_stage=list(L.heads),
+                            window_size_per_stage=list(L.window_spec), global_attention_blocks=list(L.global_att_blocks),
+                            num_query_pool_stages=L.q_pool)
+    plan, ends = L.block_plan()
+    assert ends == [1, 7, 43, 47] and len(plan) == 48
+    t = 0
+    with torch.device("meta"):
+        for s, nb in enumerate(L.stages):
+            for b in range(nb):
+                blk = Sam2MultiScaleBlock(hc, s, b, t)
+                dim, dout, heads, window, qs = plan[t]
+                assert (blk.dim, blk.dim_out, blk.attn.num_attention_heads, blk.window_size, 2 if blk.query_stride else 0) == (dim, dout, heads, window, qs), t
+                t += 1

@@ -151,3 +151,63 @@ def test_hiera_encoder_vs_oracle(gpu, H):
         assert err.max() <= 0.15 * max(1.0, scale) and err.mean() <= 0.02 * max(1.0, scale), (lvl, float(err.max()), float(err.mean()), scale)
     for lvl, r in enumerate(ref["vision_pos_enc"]):
         assert torch.equal(eng.pos_enc(lvl), torch.from_numpy(r[0]))  # input independent: bit-exact fp16
+
+
+def test_sam_features_entry_point_hiera_l(gpu, tmp_path):
+    """BASELINE configs[4] plumbing: ``python -m ...training.sam_features`` on a synthetic data directory with the full
+    Hiera-L encoder (seeded random weights), output layout of ``_save_data`` (run/dino_features.py:133-146) and values
+    against the CPU oracle on two slices.  The 256x256 tomogram is resized to the encoder's 512x512 on the GPU."""
+    from cryovit_amd import io
+    from cryovit_amd.engine.hiera import HIERA_CONFIGS, random_state_dict
+    from cryovit_amd.training import sam_features
+    from oracle import sam2_hiera as oh
+
+    rng = np.random.default_rng(4)
+    vol = rng.integers(0, 256, size=(5, 256, 256), dtype=np.uint8)
+    lab = rng.integers(-1, 2, size=vol.shape).astype(np.int8)
+    old = rng.standard_normal((8, 5, 2, 2)).astype(np.float16)
+    src = tmp_path / "processed" / "Q109"
+    src.mkdir(parents=True)
+    with io.FileWriter(src / "tomo_a.hdf") as f:
+        f.create_dataset("data", vol, compression="gzip")
+        f.create_dataset("labels/mito", lab, compression="gzip")
+        f.create_dataset("dino_features", old)
+    sam_features.main([f"paths.model_dir={tmp_path}", f"paths.data_dir={tmp_path}", f"paths.exp_dir={tmp_path / 'exp'}",
+                       "paths.feature_name=processed", "sample=Q109", "batch_size=4", "encoder.synthetic_seed=7"])
+    out = tmp_path / "tomograms" / "Q109" / "tomo_a.hdf"
+    assert out.exists(), "entry point did not produce the output tomogram (see logged traceback)"
+    assert sorted(io.list_keys(out)) == ["data", "dino_features", "labels", "sam_features"]
+    assert sorted(io.list_keys(out, "sam_features")) == ["backbone_fpn", "vision_pos_enc"]
+    assert np.array_equal(io.read_dataset(out, "data"), vol) and np.array_equal(io.read_dataset(out, "labels/mito"), lab)
+    assert np.array_equal(io.read_dataset(out, "dino_features"), old)  # the source's DINO features are kept (l.136-138)
+    cfg = HIERA_CONFIGS["sam2.1_hiera_l"]
+    sd = {k: v.cpu() for k, v in random_state_dict(cfg, 7, device=gpu).items()}
+    assert oh.HIERA_L.block_plan() == cfg.block_plan()
+    pick = [0, 4]  # both sides of the slice batch of 4
+    data = torch.from_numpy(vol[pick].astype(np.float32) / 255.0)[None, :, None].repeat(1, 1, 3, 1, 1)
+    ref = oh.sam_features(oh.HIERA_L, sd, data)
+    for lvl, g in enumerate((128, 64, 32)):
+        got = io.read_dataset(out, f"sam_features/backbone_fpn/{lvl}")
+        assert got.dtype == np.float16 and got.shape == (5, 256, g, g)
+        r = ref["backbone_fpn"][lvl].astype(np.float32)
+        err = np.abs(got[pick].astype(np.float32) - r)
+        scale = max(1.0, float(np.abs(r).mean()))
+        assert err.max() <= 0.2 * scale and err.mean() <= 0.02 * scale, (lvl, float(err.max()), float(err.mean()), scale)
+        pos = io.read_dataset(out, f"sam_features/vision_pos_enc/{lvl}")
+        assert pos.dtype == np.float16 and pos.shape == (5, 256, g, g) and np.array_equal(pos[pick], ref["vision_pos_enc"][lvl])
+
+
+def test_sam_protocol_forward_features(gpu):
+    """``model.forward_features(data [1,D,3,H,W])`` (the reference's call, run/dino_features.py:91) == the fused raw path."""
+    from cryovit_amd.models import load_sam_encoder
+    from cryovit_amd.run.dino_features import _sam_features
+
+    enc = load_sam_encoder("SAM2", synthetic_seed=5, device=gpu, slice_batch=2)
+    rng = np.random.default_rng(8)
+    vol = torch.from_numpy(rng.random((3, 512, 512), dtype=np.float32))
+    fused = _sam_features(vol, enc, 128)
+    proto = _sam_features(vol[None, :, None].repeat(1, 1, 3, 1, 1), enc, 128)
+    assert list(fused) == list(proto) == ["vision_pos_enc", "backbone_fpn"]
+    for key in fused:
+        for a, b in zip(fused[key], proto[key]):
+            assert a.dtype == b.dtype == np.float16 and a.shape == b.shape and np.array_equal(a, b)
