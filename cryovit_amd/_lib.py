@@ -12,6 +12,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libcryovit_hip.so"
 
 EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT = range(7)
 DICE_BLOCKS = 4096  # CVX_DICE_BLOCKS
+GN_BLOCKS = 1024  # CVX_GN_BLOCKS
 
 c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
 
@@ -55,6 +56,31 @@ class VitWs(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("x", "xn", "qk", "vt", "ao", "hid")]
 
 
+class HeadBlock(C.Structure):
+    _fields_ = [("c1", c_int), ("c2", c_int), ("c3", c_int), ("d1", c_int), ("d2", c_int), ("groups", c_int),
+                ("gn_w", c_void_p), ("gn_b", c_void_p),
+                ("conv1_w", c_void_p), ("conv1_b", c_void_p), ("conv1_npad", c_int), ("conv1_kpad", c_int),
+                ("conv2_w", c_void_p), ("conv2_b", c_void_p), ("conv2_npad", c_int), ("conv2_kpad", c_int),
+                ("convt_w", c_void_p), ("convt_b", c_void_p), ("convt_npad", c_int), ("convt_kpad", c_int)]
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("c_in", c_int), ("c0", c_int), ("c_tail", c_int), ("n_blocks", c_int),
+                ("proj_w", c_void_p), ("proj_b", c_void_p), ("proj_npad", c_int), ("proj_kpad", c_int),
+                ("blocks", C.POINTER(HeadBlock)),
+                ("out0_w", c_void_p), ("out0_b", c_void_p), ("out0_npad", c_int), ("out0_kpad", c_int),
+                ("out2_w", c_void_p), ("out2_b", c_float), ("zero_page", c_void_p)]
+
+
+HEAD_MAX_BLOCKS = 8
+
+
+class HeadWs(C.Structure):
+    _fields_ = [("act0", c_void_p), ("gn", c_void_p * HEAD_MAX_BLOCKS), ("t1", c_void_p * HEAD_MAX_BLOCKS),
+                ("t2", c_void_p * HEAD_MAX_BLOCKS), ("up", c_void_p * HEAD_MAX_BLOCKS), ("mid", c_void_p), ("gn_stats", c_void_p),
+                ("dice_scratch", c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/cryovit_hip.h declares
 SIGNATURES = {
     "cvx_last_error": (C.c_char_p, []),
@@ -84,6 +110,8 @@ SIGNATURES = {
     "cvx_cast_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "cvx_fpn_level_out": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cvx_dice_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
+    "cvx_head_forward": (c_int, [C.POINTER(HeadDesc), C.POINTER(HeadWs), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_float, c_void_p]),
     "cvx_vit_encode": (c_int, [C.POINTER(VitDesc), C.POINTER(VitWs), c_int, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),
 }

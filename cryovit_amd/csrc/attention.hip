@@ -55,6 +55,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     const int r = lane & 31, h = lane >> 5;
     const int q0 = qb * 128 + wave * 32;
     const int qrow = min(q0 + r, ntp - 1);  // rows past the slice are clamped for loads, never stored
+    const bool wave_idle = VARIANT != 1 && q0 >= ntok;  // (variant 1 keeps the old behaviour for A/B runs)
 
     // Q fragments: B operand of S^T = K Q^T.  lane (r,h) holds Q[q0+r][16*ks + 8*h + j]
     bf16x8 qf[4];
@@ -112,6 +113,10 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
         const char* kt = smem + (ABL_NOSYNC || ABL_NODMA ? 0 : buf) * 2 * ATT_TILE_BYTES;
         buf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
         const char* vtile = kt + ATT_TILE_BYTES;
+        // 1029 tokens = 8 x 128 + 5: in the last query block only wave 0 owns real rows.  The other three keep feeding the
+        // LDS-DMA and the barriers (the tile is a workgroup effort) but skip the products and the softmax -- their issue
+        // slots go to the other workgroups on the SIMD (wave-uniform branch: EXEC stays full).
+        if (wave_idle) continue;
 
         // ---- S^T[t] = K_t Q^T : rows = keys (registers), col = query (lane) ----
         f32x16 s[2];

@@ -164,14 +164,15 @@ __global__ __launch_bounds__(256) void k_f16_to_cl(const _Float16* __restrict__ 
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm over x[nvox][C] bf16 (channels-last), G groups of C/G adjacent channels.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x, float* __restrict__ stats, long nvox, int C,
+// Statistics are reduced WITHOUT atomics so that the result does not depend on scheduling: lane-private sums -> LDS, summed
+// per channel in thread order -> per-group block partials in global memory -> k_gn_finalize adds the blocks in a fixed order.
+__global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x, float* __restrict__ partials, long nvox, int C,
                                                   int G, long vox_per_block) {
-    extern __shared__ float red[];  // [2*C]
+    extern __shared__ float red[];  // [2*C] channel sums | channel sums of squares
+    __shared__ float part[256][17]; // one row per thread: s[8] | q[8]
     const int tid = threadIdx.x;
     const int cpt = C >> 3;         // 16-B chunks per voxel (power of two <= 256)
     const int cc = tid % cpt, vsub = tid / cpt, vstride = 256 / cpt;
-    for (int i = tid; i < 2 * C; i += 256) red[i] = 0.f;
-    __syncthreads();
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
@@ -187,18 +188,32 @@ __global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x
         }
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        atomicAdd(&red[cc * 8 + e], s[e]);
-        atomicAdd(&red[C + cc * 8 + e], q[e]);
+    for (int e = 0; e < 8; ++e) { part[tid][e] = s[e]; part[tid][8 + e] = q[e]; }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) {  // channel c (i < C: sum, else: sum of squares) over the vstride voxel lanes, in order
+        const int c = i < C ? i : i - C, col = (c & 7) + (i < C ? 0 : 8);
+        float acc = 0.f;
+        for (int vs = 0; vs < vstride; ++vs) acc += part[vs * cpt + (c >> 3)][col];
+        red[i] = acc;
     }
     __syncthreads();
     const int cpg = C / G;
-    for (int g = tid; g < G; g += 256) {
-        float ss = 0.f, qq = 0.f;
-        for (int e = 0; e < cpg; ++e) { ss += red[g * cpg + e]; qq += red[C + g * cpg + e]; }
-        atomicAdd(&stats[g], ss);
-        atomicAdd(&stats[G + g], qq);
+    for (int g = tid; g < 2 * G; g += 256) {
+        const float* src = red + (g < G ? g * cpg : C + (g - G) * cpg);
+        float acc = 0.f;
+        for (int e = 0; e < cpg; ++e) acc += src[e];
+        partials[(long)blockIdx.x * 2 * G + g] = acc;
     }
+}
+
+// stats[k] = sum over blocks of partials[b][k], k < 2G: one 64-lane group per statistic, fixed order, double accumulation
+__global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ partials, int nblk, int G2, float* __restrict__ stats) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    for (int b = lane; b < nblk; b += 64) acc += (double)partials[(long)b * G2 + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) stats[k] = (float)acc;
 }
 
 __global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x, const float* __restrict__ stats,
@@ -269,14 +284,22 @@ extern "C" int cvx_groupnorm_bf16(const void* x, const float* w, const float* b,
                                   int G, float eps, hipStream_t st) {
     if (nvox <= 0) return 0;
     const int cpt = C / 8;
-    if (C % 8 || cpt > 256 || (cpt & (cpt - 1)) || C % G) return cvx_fail("groupnorm: C must be 8*2^k <= 2048 and divisible by G");
-    CVX_HIP(hipMemsetAsync(stats, 0, sizeof(float) * 2 * G, st));
-    const long vox_per_block = 2048;
-    const unsigned nblk = (unsigned)((nvox + vox_per_block - 1) / vox_per_block);
-    hipLaunchKernelGGL(k_gn_stats, dim3(nblk), dim3(256), sizeof(float) * 2 * C, st, (const uint16_t*)x, stats, nvox, C, G,
-                       vox_per_block);
+    if (C % 8 || cpt > 256 || (cpt & (cpt - 1)) || C % G || G > 128)
+        return cvx_fail("groupnorm: C must be 8*2^k <= 2048, divisible by G, G <= 128");
+    // stats[0 .. 2G) = the sums; stats[2G ...) = per-block partials of at most CVX_GN_BLOCKS blocks
+    long nstat = (nvox + 2047) / 2048;
+    if (nstat > CVX_GN_BLOCKS) nstat = CVX_GN_BLOCKS;
+    const long vpb_stat = (nvox + nstat - 1) / nstat;
+    float* partials = stats + 2 * G;
+    hipLaunchKernelGGL(k_gn_stats, dim3((unsigned)nstat), dim3(256), sizeof(float) * 2 * C, st, (const uint16_t*)x, partials, nvox, C, G,
+                       vpb_stat);
     int rc = cvx_check_launch();
     if (rc) return rc;
+    hipLaunchKernelGGL(k_gn_finalize, dim3(2 * G), dim3(64), 0, st, partials, (int)nstat, 2 * G, stats);
+    rc = cvx_check_launch();
+    if (rc) return rc;
+    const long vox_per_block = 2048;
+    const unsigned nblk = (unsigned)((nvox + vox_per_block - 1) / vox_per_block);
     hipLaunchKernelGGL(k_gn_apply, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, stats, w, b, (uint16_t*)out, nvox, C, G,
                        eps, vox_per_block);
     return cvx_check_launch();

@@ -70,3 +70,50 @@ extern "C" int cvx_vit_encode(const cvx_vit_desc* v, const cvx_vit_ws* ws, int b
     return cvx_final_norm_features((const float*)ws->x, C, v->norm_w, v->norm_b, v->ln_eps, b, ntp, tok0, hp, wp, C, feats_f16, d_total, d0,
                                    feats_cl, tokens_f32, st);
 }
+
+
+extern "C" int cvx_head_forward(const cvx_head_desc* hd, const cvx_head_ws* ws, const void* feats_cl, int D, int h, int w, float* logits,
+                                float* probs, const int8_t* labels, float* dice, uint8_t* mask, float mask_threshold, hipStream_t st) {
+    if (!hd || !ws || !hd->blocks) return cvx_fail("head_forward: null descriptor");
+    if (hd->n_blocks < 1 || hd->n_blocks > CVX_HEAD_MAX_BLOCKS) return cvx_fail("head_forward: 1..8 synthesis blocks supported");
+    if (hd->c_tail != 8) return cvx_fail("head_forward: the fused output kernel is specialised for 8 tail channels");
+    if (D <= 0 || h <= 0 || w <= 0) return 0;
+    long nv = (long)D * h * w;
+    {
+        cvx_gemm_desc d = gemm_base(CVX_EPI_BF16_GELU, feats_cl, hd->c_in, hd->proj_w, hd->proj_kpad, nv, hd->c0, hd->proj_npad, hd->proj_kpad,
+                                    ws->act0, hd->c0, hd->proj_b);
+        CVX_TRY(cvx_gemm_bf16(&d, st));
+    }
+    const void* act = ws->act0;
+    int H = h, W = w;
+    for (int i = 0; i < hd->n_blocks; ++i) {
+        const cvx_head_block* B = &hd->blocks[i];
+        nv = (long)D * H * W;
+        CVX_TRY(cvx_groupnorm_bf16(act, B->gn_w, B->gn_b, ws->gn[i], ws->gn_stats, nv, B->c1, B->groups, 1e-3f, st));
+        {
+            cvx_conv3d_desc c = {ws->gn[i], B->conv1_w, B->conv1_b, hd->zero_page, ws->t1[i], B->c1, D, H, W, B->d1, B->c2, B->conv1_npad,
+                                 B->conv1_kpad, 1};
+            CVX_TRY(cvx_conv3d_bf16(&c, st));
+        }
+        {
+            cvx_conv3d_desc c = {ws->t1[i], B->conv2_w, B->conv2_b, hd->zero_page, ws->t2[i], B->c2, D, H, W, B->d2, B->c2, B->conv2_npad,
+                                 B->conv2_kpad, 1};
+            CVX_TRY(cvx_conv3d_bf16(&c, st));
+        }
+        {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_CONVT, ws->t2[i], B->c2, B->convt_w, B->convt_kpad, nv, 4L * B->c3, B->convt_npad, B->convt_kpad,
+                                        ws->up[i], B->c3, B->convt_b);
+            d.H = H; d.W = W; d.cout = B->c3; d.act = 1;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        act = ws->up[i];
+        H *= 2; W *= 2;
+    }
+    {
+        cvx_conv3d_desc c = {act, hd->out0_w, hd->out0_b, hd->zero_page, ws->mid, hd->c_tail, D, H, W, 1, hd->c_tail, hd->out0_npad,
+                             hd->out0_kpad, 1};
+        CVX_TRY(cvx_conv3d_bf16(&c, st));
+    }
+    return cvx_conv3_out_fused(ws->mid, hd->out2_w, hd->out2_b, logits, probs, labels, dice, ws->dice_scratch, mask, mask_threshold, D, H,
+                               W, st);
+}

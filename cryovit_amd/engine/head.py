@@ -17,7 +17,9 @@ from __future__ import annotations
 
 import torch
 
-from cryovit_amd._lib import EPI_BF16_GELU, EPI_CONVT
+import ctypes as C
+
+from cryovit_amd._lib import EPI_BF16_GELU, EPI_CONVT, HeadBlock, HeadDesc, HeadWs, check
 from cryovit_amd.engine import ops
 from cryovit_amd.engine.ops import round_up
 
@@ -100,8 +102,49 @@ class HeadEngine:
         self.o2_b = float(sd["output_layer.2.bias"][0])
         self.w = w
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
-        self.stats = torch.zeros(2 * 256, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(ops.gn_stats_size(128), dtype=torch.float32, device=self.device)
         self._ws = {}
+        self._desc = self._make_desc()
+
+    def _make_desc(self) -> HeadDesc:
+        """Weight table for ``cvx_head_forward`` (host struct of device pointers; the tensors stay owned by ``self``)."""
+        c_in, blocks, c_tail = self.widths
+        W = self.w
+        d = HeadDesc()
+        d.c_in, d.c0, d.c_tail, d.n_blocks = c_in, blocks[0][0], c_tail, len(blocks)
+        d.proj_w, d.proj_b, d.proj_npad, d.proj_kpad = W["proj_w"].data_ptr(), W["proj_b"].data_ptr(), *W["proj_w"].shape
+        self._cblocks = (HeadBlock * len(blocks))()
+        for cb, blk in zip(self._cblocks, self.blocks):
+            cb.c1, cb.c2, cb.c3, cb.d1, cb.d2 = blk["c"]
+            cb.groups = blk["G"]
+            cb.gn_w, cb.gn_b = blk["gn_w"].data_ptr(), blk["gn_b"].data_ptr()
+            cb.conv1_w, cb.conv1_b, cb.conv1_npad, cb.conv1_kpad = blk["c1_w"].data_ptr(), blk["c1_b"].data_ptr(), *blk["c1_w"].shape
+            cb.conv2_w, cb.conv2_b, cb.conv2_npad, cb.conv2_kpad = blk["c2_w"].data_ptr(), blk["c2_b"].data_ptr(), *blk["c2_w"].shape
+            cb.convt_w, cb.convt_b, cb.convt_npad, cb.convt_kpad = blk["ct_w"].data_ptr(), blk["ct_b"].data_ptr(), *blk["ct_w"].shape
+        d.blocks = C.cast(self._cblocks, C.POINTER(HeadBlock))
+        d.out0_w, d.out0_b, d.out0_npad, d.out0_kpad = W["o0_w"].data_ptr(), W["o0_b"].data_ptr(), *W["o0_w"].shape
+        d.out2_w, d.out2_b, d.zero_page = W["o2_w"].data_ptr(), self.o2_b, self.zero_page.data_ptr()
+        return d
+
+    def _make_ws(self, D: int, h: int, w_: int) -> HeadWs:
+        key = ("ws", D, h, w_)
+        if key not in self._ws:
+            _, blocks, c_tail = self.widths
+            ws = HeadWs()
+            ws.act0 = self._buf("a", D * h * w_, blocks[0][0]).data_ptr()
+            H_, W_ = h, w_
+            for bi, (c1, c2, c3, _, _) in enumerate(blocks):
+                nv = D * H_ * W_
+                ws.gn[bi] = self._buf(f"g{bi}", nv, c1).data_ptr()
+                ws.t1[bi] = self._buf(f"t1_{bi}", nv, c2).data_ptr()
+                ws.t2[bi] = self._buf(f"t2_{bi}", nv, c2).data_ptr()
+                ws.up[bi] = self._buf(f"u{bi}", nv * 4, c3).data_ptr()
+                H_, W_ = 2 * H_, 2 * W_
+            ws.mid = self._buf("mid", D * H_ * W_, c_tail).data_ptr()
+            ws.gn_stats = self.stats.data_ptr()
+            ws.dice_scratch = ops.dice_scratch(self.device).data_ptr()
+            self._ws[key] = ws
+        return self._ws[key]
 
     def clone_for_stream(self) -> "HeadEngine":
         """Second launch context over the same packed weights with private activation buffers (one per HIP stream)."""
@@ -109,6 +152,7 @@ class HeadEngine:
         other.__dict__.update(self.__dict__)
         other._ws = {}
         other.stats = torch.zeros_like(self.stats)
+        other._desc = other._make_desc()
         return other
 
     def _buf(self, name: str, rows: int, ch: int) -> torch.Tensor:
@@ -122,7 +166,28 @@ class HeadEngine:
                 mask_threshold: float | None = None):
         """feats_cl: bf16 channels-last features [D*h*w (+slack rows), C_in].  Returns dict with
         ``probs`` / ``logits`` fp32 [D, 16h, 16w], ``dice_sums`` (fp32[3] device tensor) when labels are given and
-        ``mask`` uint8 [D, 16h, 16w] = (probs >= mask_threshold) when a threshold is given."""
+        ``mask`` uint8 [D, 16h, 16w] = (probs >= mask_threshold) when a threshold is given.  ONE C call: cvx_head_forward."""
+        c_in, blocks, _ = self.widths
+        ops._dev_check(feats_cl, labels)
+        if feats_cl.dtype != torch.bfloat16 or feats_cl.numel() < ops.alloc_rows(D * h * w_) * c_in:
+            raise ops._lib.CvxError("head: features must be bf16 [rup(D*h*w,256)+256 rows][c_in]")
+        up = 2 ** len(blocks)
+        shape = (D, h * up, w_ * up)
+        dev = self.device
+        logits = torch.empty(shape, dtype=torch.float32, device=dev) if want_logits else None
+        probs = torch.empty(shape, dtype=torch.float32, device=dev) if want_probs else None
+        mask = torch.empty(shape, dtype=torch.uint8, device=dev) if mask_threshold is not None else None
+        dice = torch.zeros(3, dtype=torch.float32, device=dev) if labels is not None else None
+        if labels is not None and (labels.dtype != torch.int8 or tuple(labels.shape) != shape):
+            raise ops._lib.CvxError(f"head: labels must be int8 {shape}")
+        check(ops._lib.load().cvx_head_forward(C.byref(self._desc), C.byref(self._make_ws(D, h, w_)), feats_cl.data_ptr(), D, h, w_,
+                                               ops._p(logits), ops._p(probs), ops._p(labels), ops._p(dice), ops._p(mask),
+                                               0.5 if mask_threshold is None else float(mask_threshold), ops._stream()), "cvx_head_forward")
+        return {"logits": logits, "probs": probs, "dice_sums": dice, "mask": mask}
+
+    def _forward_py(self, feats_cl: torch.Tensor, D: int, h: int, w_: int, labels=None, want_logits=False, want_probs=True,
+                    mask_threshold: float | None = None):
+        """The same launch sequence spelled out with the op-level entry points (what cvx_head_forward does; kept for A/B tests)."""
         c_in, blocks, c_tail = self.widths
         W = self.w
         nvox = D * h * w_

@@ -123,9 +123,15 @@ def features_to_channels_last(feats_f16: torch.Tensor, out_cl: torch.Tensor) -> 
           "cvx_features_to_channels_last")
 
 
+def gn_stats_size(G: int) -> int:
+    return 2 * G * (1 + _lib.GN_BLOCKS)
+
+
 def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, stats: torch.Tensor, *, nvox: int,
               Cdim: int, G: int, eps: float) -> None:
     _dev_check(x, w, b, out, stats)
+    if stats.dtype != torch.float32 or stats.numel() < gn_stats_size(G):
+        raise _lib.CvxError(f"groupnorm: stats must be fp32 with >= {gn_stats_size(G)} elements (2*G*(1+CVX_GN_BLOCKS))")
     check(_lib.load().cvx_groupnorm_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(), nvox, Cdim,
                                          G, eps, _stream()), "cvx_groupnorm_bf16")
 
@@ -133,15 +139,18 @@ def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tens
 _dice_scratch = {}
 
 
+def dice_scratch(device) -> torch.Tensor:
+    """Per (device, stream) partial-sum buffer of the fused output kernel (two volumes may be in flight on two streams)."""
+    key = (torch.device(device), _stream())
+    if key not in _dice_scratch:
+        _dice_scratch[key] = torch.zeros(3 * _lib.DICE_BLOCKS, dtype=torch.float32, device=device)
+    return _dice_scratch[key]
+
+
 def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs, labels, dice, *, D: int, H: int, W: int,
                     mask=None, mask_threshold: float = 0.5) -> None:
     _dev_check(x, w, logits, probs, labels, dice, mask)
-    scratch = None
-    if labels is not None:
-        key = (x.device, _stream())  # per stream: two volumes may be in flight at once
-        scratch = _dice_scratch.get(key)
-        if scratch is None:
-            scratch = _dice_scratch[key] = torch.zeros(3 * _lib.DICE_BLOCKS, dtype=torch.float32, device=x.device)
+    scratch = dice_scratch(x.device) if labels is not None else None
     check(_lib.load().cvx_conv3_out_fused(x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), _p(labels), _p(dice),
                                           _p(scratch), _p(mask), float(mask_threshold), D, H, W, _stream()), "cvx_conv3_out_fused")
 

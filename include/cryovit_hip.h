@@ -138,9 +138,11 @@ int cvx_im2col_patches(const float* x, int b, int Hi, int Wi, void* out, int k_p
 /* fp16 [C][D][h][w] (the HDF5 `dino_features` layout) -> bf16 channels-last [D][h][w][C] */
 int cvx_features_to_channels_last(const void* feats_f16, void* out_cl, int C, long nvox, hipStream_t stream);
 
-/* GroupNorm over a channels-last bf16 volume x[nvox][C], G groups, biased variance, eps inside sqrt
- * (nn.GroupNorm(G, C, eps=1e-3) -- cryovit.py:69).  Two launches: stats (sum, sumsq per group into
- * stats[2*G] fp32, zeroed by the call) then apply -> bf16 out. */
+/* GroupNorm over a channels-last bf16 volume x[nvox][C], G groups (<= 128), biased variance, eps inside sqrt
+ * (nn.GroupNorm(G, C, eps=1e-3) -- cryovit.py:69).  Three launches: per-block partial sums, fixed-order reduction (no
+ * atomics: results are bitwise reproducible), apply -> bf16 out.  stats: fp32 scratch of 2*G*(1 + CVX_GN_BLOCKS) floats
+ * (stats[0..2G) = sum | sum of squares per group after the call). */
+#define CVX_GN_BLOCKS 1024
 int cvx_groupnorm_bf16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
                        int G, float eps, hipStream_t stream);
 
@@ -238,6 +240,48 @@ typedef struct cvx_vit_ws {        /* device workspaces, rows = rup(b*ntp,256)+2
 int cvx_vit_encode(const cvx_vit_desc* vit, const cvx_vit_ws* ws, int b, int hp, int wp, const void* patches, long patches_ld,
                    const void* pe_w, const float* pos, const float* cls_pos0, void* feats_f16, long d_total, long d0,
                    void* feats_cl, float* tokens_f32, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The whole CryoVIT segmentation head as ONE call: Conv3d(c_in -> c0, k=1) + GELU, n_blocks x SynthesisBlock { GroupNorm(eps
+ * 1e-3), dilated Conv3d + GELU, dilated Conv3d + GELU, ConvTranspose3d (1,2,2) + GELU }, Conv3d(8,8,3) + GELU, Conv3d(8,1,3),
+ * clip(+-5), sigmoid, masked Dice sums and the thresholded uint8 segmentation.  Replaces CryoVIT.forward_volume / forward
+ * (src/cryovit/models/cryovit.py:36-49), the reductions of base_model.py:99-110 / metrics.py:36-41 and PredictionWriter's
+ * threshold (callbacks.py:100-102).  Weights packed as documented for cvx_gemm_bf16 / cvx_conv3d_bf16.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct cvx_head_block {
+    int c1, c2, c3, d1, d2, groups;           /* SynthesisBlock(c1, c2, c3, d1, d2); groups = max(8, c1/8) */
+    const float *gn_w, *gn_b;                 /* fp32 [c1] */
+    const void* conv1_w; const float* conv1_b; int conv1_npad, conv1_kpad;   /* bf16 [npad][rup(27*c1,64)] */
+    const void* conv2_w; const float* conv2_b; int conv2_npad, conv2_kpad;   /* bf16 [npad][rup(27*c2,64)] */
+    const void* convt_w; const float* convt_b; int convt_npad, convt_kpad;   /* bf16 [npad(4*c3)][rup(c2,64)], row (i*2+j)*c3 + o */
+} cvx_head_block;
+
+typedef struct cvx_head_desc {
+    int c_in, c0, c_tail, n_blocks;           /* c_tail must be 8 */
+    const void* proj_w; const float* proj_b; int proj_npad, proj_kpad;
+    const cvx_head_block* blocks;             /* HOST array of n_blocks entries (device pointers inside) */
+    const void* out0_w; const float* out0_b; int out0_npad, out0_kpad;        /* Conv3d(8,8,3) */
+    const float* out2_w; float out2_b;        /* Conv3d(8,1,3): fp32 [27][8] tap-major, scalar bias */
+    const void* zero_page;                    /* >= 256 zero bytes */
+} cvx_head_desc;
+
+#define CVX_HEAD_MAX_BLOCKS 8
+typedef struct cvx_head_ws {                  /* device workspaces, bf16 channels-last, rows = rup(voxels,256)+256 (+2048 elements) */
+    void* act0;                               /* [D*h*w rows][c0] */
+    void* gn[CVX_HEAD_MAX_BLOCKS];            /* block i input resolution rows x c1 */
+    void* t1[CVX_HEAD_MAX_BLOCKS];            /* rows x c2 */
+    void* t2[CVX_HEAD_MAX_BLOCKS];            /* rows x c2 */
+    void* up[CVX_HEAD_MAX_BLOCKS];            /* 4*rows x c3 */
+    void* mid;                                /* full-resolution rows x 8 */
+    float* gn_stats;                          /* fp32 [2*G_max*(1+CVX_GN_BLOCKS)], G_max = 128 */
+    float* dice_scratch;                      /* fp32 [3*CVX_DICE_BLOCKS] (only read when labels != NULL) */
+} cvx_head_ws;
+
+/* feats_cl: bf16 channels-last features [D*h*w (+pad rows)][c_in] (cvx_vit_encode's feats_cl or
+ * cvx_features_to_channels_last).  Outputs at 2^n_blocks x the in-plane resolution, all nullable: logits / probs fp32,
+ * dice fp32[3] (+=, needs labels int8), mask uint8 (probs >= mask_threshold). */
+int cvx_head_forward(const cvx_head_desc* head, const cvx_head_ws* ws, const void* feats_cl, int D, int h, int w, float* logits,
+                     float* probs, const int8_t* labels, float* dice, uint8_t* mask, float mask_threshold, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,12 @@ def test_head_narrow_golden(gpu, gold):
     dice = 2 * i / (sy + sp + 1e-3)
     near = int(((ref.abs() < 5e-2) & (torch.from_numpy(g["labels"]) > -1)).sum())
     assert abs(dice - float(g["dice"])) <= 1e-3, (dice, float(g["dice"]), f"{near} voxels within tolerance of the threshold")
+    # the single C call (cvx_head_forward) and the op-by-op launch list are the same kernels in the same order: bit-identical
+    py = eng._forward_py(cl, D, h, w, labels=labels, want_logits=True, mask_threshold=0.5)
+    one = eng.forward(cl, D, h, w, labels=labels, want_logits=True, mask_threshold=0.5)
+    for k in ("logits", "probs", "dice_sums", "mask"):
+        assert torch.equal(py[k], one[k]), k
+    assert torch.equal(one["mask"], (one["probs"] >= 0.5).to(torch.uint8))
 
 
 def test_synthesis_block_golden(gpu, gold):
@@ -115,7 +121,7 @@ def test_synthesis_block_golden(gpu, gold):
     t = lambda k: torch.from_numpy(g[k])  # noqa: E731
     xin = x.permute(1, 2, 3, 0).reshape(nv, C).contiguous().to(torch.bfloat16).to(gpu)
     zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
-    stats = torch.zeros(16, device=gpu)
+    stats = torch.zeros(ops.gn_stats_size(8), device=gpu)
     gn = torch.zeros_like(xin)
     ops.groupnorm(xin, t("layers_0_weight").to(gpu), t("layers_0_bias").to(gpu), gn, stats, nvox=nv, Cdim=32, G=8, eps=1e-3)
     t1 = torch.zeros(nv, 16, dtype=torch.bfloat16, device=gpu)

@@ -258,10 +258,36 @@ def test_groupnorm(gpu, C, G):
     x = bf(rnd(D, H, W, C, seed=35) * 1.5 + 0.4)
     w, b = rnd(C, seed=36) + 1, rnd(C, seed=37)
     out = torch.zeros_like(x, device=gpu)
-    stats = torch.zeros(2 * G, device=gpu)
+    stats = torch.zeros(ops.gn_stats_size(G), device=gpu)
     ops.groupnorm(x.to(gpu), w.to(gpu), b.to(gpu), out, stats, nvox=D * H * W, Cdim=C, G=G, eps=1e-3)
     ref = F.group_norm(x.float().permute(3, 0, 1, 2).unsqueeze(0), G, w, b, 1e-3)[0].permute(1, 2, 3, 0)
     assert torch.allclose(out.float().cpu(), ref, atol=3e-2, rtol=1e-2), float((out.float().cpu() - ref).abs().max())
+
+
+def test_groupnorm_many_blocks_reproducible(gpu):
+    """More voxels than CVX_GN_BLOCKS * 2048 (blocks take several chunks) and a fixed-order reduction: the group sums match
+    float64 sums of the bf16 inputs to fp32 round-off and repeated calls are bit-identical (no atomics)."""
+    from cryovit_amd.engine import ops
+
+    C, G, nvox = 16, 8, 1024 * 2048 + 12345
+    g = torch.Generator(device=gpu).manual_seed(5)
+    x = (torch.randn(nvox, C, device=gpu, generator=g) * 2 + 0.3).to(torch.bfloat16)
+    w, b = torch.ones(C, device=gpu), torch.zeros(C, device=gpu)
+    stats = torch.zeros(ops.gn_stats_size(G), device=gpu)
+    outs = []
+    for _ in range(3):
+        out = torch.empty_like(x)
+        ops.groupnorm(x, w, b, out, stats, nvox=nvox, Cdim=C, G=G, eps=1e-3)
+        outs.append((out.clone(), stats[: 2 * G].clone()))
+    assert all(torch.equal(outs[0][0], o) and torch.equal(outs[0][1], s) for o, s in outs[1:])
+    xd = x.double().reshape(nvox, G, C // G)
+    want = torch.cat([xd.sum((0, 2)), (xd * xd).sum((0, 2))]).cpu()
+    got = outs[0][1].double().cpu()
+    assert torch.allclose(got, want, rtol=1e-6), (got, want)
+    mean = want[:G] / (nvox * 2)
+    var = want[G:] / (nvox * 2) - mean**2
+    ref = ((x[:4096].float().cpu().reshape(-1, G, 2) - mean.float()[None, :, None]) / torch.sqrt(var.float() + 1e-3)[None, :, None]).reshape(-1, C)
+    assert torch.allclose(outs[0][0][:4096].float().cpu(), ref, atol=3e-2, rtol=1e-2)
 
 
 @pytest.mark.parametrize("Cin,Cout,dil,D,H,W", [(128, 24, 32, 8, 4, 4), (32, 16, 2, 6, 8, 8), (8, 8, 1, 5, 9, 11), (192, 192, 3, 7, 5, 6),
