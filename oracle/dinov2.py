@@ -149,14 +149,62 @@ def block_forward(cfg: VitCfg, sd: dict, i: int, x: torch.Tensor) -> torch.Tenso
     return x + sd[p + "ls2.gamma"] * m
 
 
+def _bf(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).float()
+
+
+@torch.inference_mode()
+def forward_features_bf16_storage(cfg: VitCfg, sd: dict, x: torch.Tensor) -> dict[str, torch.Tensor]:
+    """The same network with exact (fp32) arithmetic but every tensor the HIP path STORES in bf16 rounded to bf16: GEMM
+    operands (LayerNorm outputs, weights, patch pixels), q/k/v, the softmax probabilities fed to the PV product, the
+    attention output and the FFN hidden activations; the residual stream, accumulators, softmax statistics and norms stay
+    fp32.  It separates what bf16 storage costs (any implementation with this storage plan) from what the kernels add."""
+    b, _, H, W = x.shape
+    hp, wp = H // cfg.patch, W // cfg.patch
+    C, nh, hd = cfg.dim, cfg.heads, cfg.head_dim
+    t = F.conv2d(_bf(x), _bf(sd["patch_embed.proj.weight"]), sd["patch_embed.proj.bias"], stride=cfg.patch).flatten(2).transpose(1, 2)
+    t = torch.cat([sd["cls_token"].expand(b, -1, -1), t], dim=1) + interpolate_pos_embed(cfg, sd["pos_embed"], hp, wp)
+    t = torch.cat([t[:, :1], sd["register_tokens"].expand(b, -1, -1), t[:, 1:]], dim=1)
+    N = t.shape[1]
+    for i in range(cfg.depth):
+        p = f"blocks.{i}."
+        h = _bf(F.layer_norm(t, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], cfg.ln_eps))
+        w = sd[p + "attn.qkv.weight"].clone()
+        bias = sd[p + "attn.qkv.bias"].clone()
+        w[:C] *= hd**-0.5  # the engine folds the (power-of-two) scale into the q rows before rounding: exact
+        bias[:C] *= hd**-0.5
+        qkv = _bf(F.linear(h, _bf(w), bias)).reshape(b, N, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        sc = q @ k.transpose(-2, -1)
+        m = sc.amax(-1, keepdim=True)
+        e = torch.exp(sc - m)
+        a = (_bf(e) @ v) / e.sum(-1, keepdim=True)  # probabilities are rounded after exp(s - max), the sum stays fp32
+        a = _bf(a.transpose(1, 2).reshape(b, N, C))
+        t = t + sd[p + "ls1.gamma"] * F.linear(a, _bf(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
+        h = _bf(F.layer_norm(t, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], cfg.ln_eps))
+        if cfg.ffn == "swiglu":
+            x1, x2 = F.linear(h, _bf(sd[p + "mlp.w12.weight"]), sd[p + "mlp.w12.bias"]).chunk(2, dim=-1)
+            mm = F.linear(_bf(F.silu(x1) * x2), _bf(sd[p + "mlp.w3.weight"]), sd[p + "mlp.w3.bias"])
+        else:
+            mm = F.linear(_bf(F.gelu(F.linear(h, _bf(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"]))), _bf(sd[p + "mlp.fc2.weight"]),
+                          sd[p + "mlp.fc2.bias"])
+        t = t + sd[p + "ls2.gamma"] * mm
+    pre = t
+    t = F.layer_norm(t, (C,), sd["norm.weight"], sd["norm.bias"], cfg.ln_eps)
+    return {"x_prenorm": pre, "x_norm_clstoken": t[:, 0], "x_norm_regtokens": t[:, 1 : 1 + cfg.n_reg],
+            "x_norm_patchtokens": t[:, 1 + cfg.n_reg :]}
+
+
 @torch.inference_mode()
 def forward_features(cfg: VitCfg, sd: dict, x: torch.Tensor) -> dict[str, torch.Tensor]:
     """``[b,3,H',W'] fp32 -> {"x_norm_patchtokens": [b, hp*wp, C], ...}`` (App. A-4)."""
     t = embed_tokens(cfg, sd, x)
     for i in range(cfg.depth):
         t = block_forward(cfg, sd, i, t)
+    pre = t
     t = F.layer_norm(t, (cfg.dim,), sd["norm.weight"], sd["norm.bias"], cfg.ln_eps)
     return {
+        "x_prenorm": pre,
         "x_norm_clstoken": t[:, 0],
         "x_norm_regtokens": t[:, 1 : 1 + cfg.n_reg],
         "x_norm_patchtokens": t[:, 1 + cfg.n_reg :],

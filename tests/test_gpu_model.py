@@ -50,8 +50,12 @@ def test_vit_tiny_golden(gpu, gold, name):
     eng = VitEngine(_engine_cfg(ocfg), sd, gpu)
     # the fixture input is an already-resized [b,56,84] image: feed it through the protocol entry point
     x = torch.from_numpy(g["x"])  # [2,56,84] one channel (3 identical)
-    tok = eng.forward_features(x.unsqueeze(1).expand(-1, 3, -1, -1).contiguous().to(gpu))["x_norm_patchtokens"]
+    x3 = x.unsqueeze(1).expand(-1, 3, -1, -1).contiguous()
+    tok = eng.forward_features(x3.to(gpu))["x_norm_patchtokens"]
     _check_tokens(tok.float().cpu(), torch.from_numpy(g["tokens"]))
+    # vs the oracle with the same bf16 storage points (exact arithmetic): the kernels add almost nothing on top of storage
+    emu = o.forward_features_bf16_storage(ocfg, sd, x3)["x_norm_patchtokens"]
+    _check_tokens(tok.float().cpu(), emu, max_tol=2e-2, mean_tol=2e-3)
 
 
 def test_vit_s_raw_slices_vs_oracle(gpu):
@@ -71,6 +75,49 @@ def test_vit_s_raw_slices_vs_oracle(gpu):
     eng.features(sl[:2], feats_f16=f16, d_total=D, d0=0)  # two slice batches, like the reference's batch loop
     eng.features(sl[2:], feats_f16=f16, d_total=D, d0=2)
     _check_tokens(f16.float().cpu(), torch.from_numpy(ref.astype(np.float32)))
+
+
+def test_vit_s_outlier_channels_vs_oracle(gpu):
+    """Pretrained DINOv2 weights are not N(0, 0.02): the residual stream carries a few massive channels, LayerScale gains
+    span orders of magnitude and the softmax is sharper.  No checkpoint is reachable offline, so that stress is built
+    synthetically on ViT-S: 6 residual channels driven 50x (proj / fc2 rows), LayerScale over ~3 decades, LayerNorm gains in
+    [0.1, 5], q/k projections x2 each.  The fp32 oracle's pre-norm stream then peaks at ~150x its median.
+    Two references: the fp32 oracle, and the oracle with exact arithmetic but the HIP path's bf16 STORAGE points
+    (``forward_features_bf16_storage``).  Storage alone moves single outputs by ~0.55 here (measured: emulation vs fp32), so
+    the bound vs fp32 is "no worse than storage costs" (1.25x that + 0.05; mean <= 1e-2), and the kernels must stay close
+    to the storage emulation (measured on MI355X: max 0.17 / mean 0.0016 -- what remains is fp32 summation order and the
+    exp2 / erf approximations, amplified by the sharp softmax)."""
+    from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine
+    from oracle import dinov2 as o
+    from oracle import preprocess as opre
+
+    sd = o.init_state_dict(o.VITS14_REG, 61)
+    g = torch.Generator().manual_seed(62)
+    C = 384
+    hot = torch.randperm(C, generator=g)[:6]
+    sd["patch_embed.proj.bias"][hot] += 3.0
+    for i in range(12):
+        p = f"blocks.{i}."
+        sd[p + "attn.proj.weight"][hot] *= 50.0
+        sd[p + "mlp.fc2.weight"][hot] *= 50.0
+        sd[p + "ls1.gamma"] = torch.exp(torch.randn(C, generator=g) * 1.5) * 0.3
+        sd[p + "ls2.gamma"] = torch.exp(torch.randn(C, generator=g) * 1.5) * 0.3
+        sd[p + "norm1.weight"] = torch.exp(torch.rand(C, generator=g) * 3.9 - 2.3)
+        sd[p + "norm2.weight"] = torch.exp(torch.rand(C, generator=g) * 3.9 - 2.3)
+        sd[p + "attn.qkv.weight"][: 2 * C] *= 2.0
+    vol = np.random.default_rng(63).integers(0, 256, size=(2, 64, 96), dtype=np.uint8)
+    x = opre.dino_transform(opre.load_scale(vol))
+    f32 = o.forward_features(o.VITS14_REG, sd, x)
+    emu = o.forward_features_bf16_storage(o.VITS14_REG, sd, x)["x_norm_patchtokens"]
+    assert float(f32["x_prenorm"].abs().max()) > 100 * float(f32["x_prenorm"].abs().median())  # the stress is real
+    ref = f32["x_norm_patchtokens"]
+    eng = VitEngine(VIT_CONFIGS["dinov2_vits14_reg"], sd, gpu)
+    got = eng.forward_features(x.to(gpu))["x_norm_patchtokens"].float().cpu()
+    assert torch.isfinite(got).all()
+    e_emu, e_f32 = (got - emu).abs(), (got - ref).abs()
+    stats = (float(e_emu.max()), float(e_emu.mean()), float(e_f32.max()), float(e_f32.mean()), float((emu - ref).abs().max()))
+    assert float(e_f32.max()) <= 1.25 * stats[4] + 5e-2 and float(e_f32.mean()) <= 1e-2, stats
+    assert float(e_emu.max()) <= 2.5e-1 and float(e_emu.mean()) <= 5e-3, stats
 
 
 def test_head_narrow_golden(gpu, gold):
