@@ -174,7 +174,7 @@ def main() -> None:
     labels = synthetic_labels(dev, 4 + rank)
     hp, wp = H_ // 16, W_ // 16
     nvox_feat = D_ * hp * wp
-    feats_cl = torch.zeros(ops.alloc_rows(nvox_feat), cfg.dim, dtype=torch.bfloat16, device=dev)
+    feats_cl = torch.zeros(ops.alloc_rows(nvox_feat), cfg.dim, dtype=torch.float16, device=dev)
     feats_f16 = torch.zeros(cfg.dim, D_, hp, wp, dtype=torch.float16, device=dev)  # the on-disk `dino_features` tensor
     sb = args.slice_batch
 

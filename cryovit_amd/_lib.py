@@ -11,6 +11,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libcryovit_hip.so"
 
 EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT = range(7)
+DTYPE_BF16, DTYPE_F16 = 0, 1  # CVX_DTYPE_*
 DICE_BLOCKS = 4096  # CVX_DICE_BLOCKS
 GN_BLOCKS = 1024  # CVX_GN_BLOCKS
 
@@ -29,7 +30,7 @@ class GemmDesc(C.Structure):
         ("pos", c_void_p), ("ldpos", c_long),
         ("npatch", c_int), ("ntp", c_int), ("tok0", c_int),
         ("heads", c_int), ("kp", c_int),
-        ("H", c_int), ("W", c_int), ("cout", c_int), ("act", c_int),
+        ("H", c_int), ("W", c_int), ("cout", c_int), ("act", c_int), ("dtype", c_int),
     ]
 
 
@@ -91,7 +92,7 @@ SIGNATURES = {
     "cvx_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "cvx_set_gemm_event_hook": (c_int, [c_int, c_void_p, c_void_p, c_int]),
     "cvx_get_gemm_event_count": (c_int, []),
-    "cvx_conv3d_bf16": (c_int, [C.POINTER(Conv3dDesc), c_void_p]),
+    "cvx_conv3d_f16": (c_int, [C.POINTER(Conv3dDesc), c_void_p]),
     "cvx_layernorm_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
     "cvx_attention_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cvx_preprocess_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -100,7 +101,7 @@ SIGNATURES = {
                                         c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),
     "cvx_im2col_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "cvx_features_to_channels_last": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
-    "cvx_groupnorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
+    "cvx_groupnorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
     "cvx_conv3_out_fused": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                     c_int, c_int, c_int, c_void_p]),
     "cvx_sam_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p]),

@@ -21,6 +21,28 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+// fp16 storage (the segmentation head: the reference runs it under fp16 autocast, configs `precision: "16-mixed"`).
+// Conversions saturate at the largest finite half instead of producing inf.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ uint16_t f2h(float f) {
+    _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f);
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) { return (uint32_t)f2h(lo) | ((uint32_t)f2h(hi) << 16); }
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ float hlo(uint32_t w) { return h2f((uint16_t)(w & 0xffff)); }
+__device__ __forceinline__ float hhi(uint32_t w) { return h2f((uint16_t)(w >> 16)); }
+template <bool F16> __device__ __forceinline__ uint32_t pack2x(float lo, float hi) { return F16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+
+// v_mfma_f32_16x16x32 on bf16 or fp16 operands (same register layouts; the LDS images are type-agnostic 16-bit data)
+template <bool F16> __device__ __forceinline__ f32x4 mfma16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// epilogues that store fp16 (and therefore consume fp16 operands) declare `static constexpr bool F16 = true`
+template <class E, class = void> struct epi_is_f16 { static constexpr bool value = false; };
+template <class E> struct epi_is_f16<E, decltype((void)E::F16)> { static constexpr bool value = E::F16; };
+
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

@@ -15,17 +15,17 @@ namespace cvx {
 // Epilogues.  NREG orientation: store<NV>(n0, m, v) -- v[i] is output feature n0+i of row m.
 //             MREG orientation: store<NV>(m0, n, v) -- v[i] is row m0+i of output feature n.
 // ------------------------------------------------------------------------------------------------
-template <int NV>
+template <int NV, bool F16 = false>
 __device__ __forceinline__ void store_bf16_chunked(uint16_t* dst, const float* v, long n0, long n_valid) {
     if constexpr (NV >= 8) {
 #pragma unroll
         for (int h = 0; h < NV / 8; ++h) {
             if (n0 + h * 8 < n_valid) {
                 uint4 w;
-                w.x = pack2bf(v[h * 8 + 0], v[h * 8 + 1]);
-                w.y = pack2bf(v[h * 8 + 2], v[h * 8 + 3]);
-                w.z = pack2bf(v[h * 8 + 4], v[h * 8 + 5]);
-                w.w = pack2bf(v[h * 8 + 6], v[h * 8 + 7]);
+                w.x = pack2x<F16>(v[h * 8 + 0], v[h * 8 + 1]);
+                w.y = pack2x<F16>(v[h * 8 + 2], v[h * 8 + 3]);
+                w.z = pack2x<F16>(v[h * 8 + 4], v[h * 8 + 5]);
+                w.w = pack2x<F16>(v[h * 8 + 6], v[h * 8 + 7]);
                 *(uint4*)(dst + h * 8) = w;
             }
         }
@@ -33,8 +33,8 @@ __device__ __forceinline__ void store_bf16_chunked(uint16_t* dst, const float* v
         static_assert(NV == 4, "NV must be 4 or a multiple of 8");
         if (n0 < n_valid) {
             uint2 w;
-            w.x = pack2bf(v[0], v[1]);
-            w.y = pack2bf(v[2], v[3]);
+            w.x = pack2x<F16>(v[0], v[1]);
+            w.y = pack2x<F16>(v[2], v[3]);
             *(uint2*)dst = w;
         }
     }
@@ -54,9 +54,10 @@ __device__ __forceinline__ void load_vec(float* dst, const float* src) {
     }
 }
 
-// out[m][n] = bf16(act(acc + bias[n]));  ACT: 0 none, 1 GELU(erf)
-template <int ACT>
+// out[m][n] = bf16 | fp16 (act(acc + bias[n]));  ACT: 0 none, 1 GELU(erf);  HALF: fp16 operands and output (the head)
+template <int ACT, bool HALF = false>
 struct EpiBF16 {
+    static constexpr bool F16 = HALF;
     uint16_t* out; long ldc; const float* bias; long m_valid, n_valid;
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
@@ -70,7 +71,7 @@ struct EpiBF16 {
             const float t = acc[i] + c.bias[i];
             v[i] = ACT == 1 ? gelu_erf(t) : t;
         }
-        store_bf16_chunked<NV>(out + m * ldc + n0, v, n0, n_valid);
+        store_bf16_chunked<NV, HALF>(out + m * ldc + n0, v, n0, n_valid);
     }
     // the same epilogue for rows [m_off, ...) of the problem when A is passed advanced by m_off rows (tail launches)
     EpiBF16 shifted(long m_off) const { return EpiBF16{out + m_off * ldc, ldc, bias, m_valid - m_off, n_valid}; }
@@ -80,7 +81,7 @@ struct EpiBF16 {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const float a = acc[2 * i] + c.bias[2 * i], b = acc[2 * i + 1] + c.bias[2 * i + 1];
-            w[i] = pack2bf(ACT == 1 ? gelu_erf(a) : a, ACT == 1 ? gelu_erf(b) : b);
+            w[i] = pack2x<HALF>(ACT == 1 ? gelu_erf(a) : a, ACT == 1 ? gelu_erf(b) : b);
         }
     }
 };
@@ -212,8 +213,9 @@ struct EpiVT {
 
 // ConvTranspose3d kernel=stride=(1,2,2) as a GEMM with N = 4*Cout (n = (i*2+j)*Cout + o), pixel-shuffle
 // scatter into the channels-last output [D][2H][2W][Cout], GELU fused.  bias is pre-expanded to N entries.
-template <int ACT>
+template <int ACT, bool HALF = false>
 struct EpiConvT {
+    static constexpr bool F16 = HALF;
     uint16_t* out; const float* bias; int H, W, cout; long m_valid, n_valid;
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
@@ -235,7 +237,7 @@ struct EpiConvT {
                 v[i] = ACT == 1 ? gelu_erf(tt) : tt;
             }
             uint16_t* dst = out + ((zq * (2L * H) + 2 * yq + (ij >> 1)) * (2L * W) + 2 * xq + (ij & 1)) * cout + o;
-            store_bf16_chunked<CH>(dst, v, 0, 1);
+            store_bf16_chunked<CH, HALF>(dst, v, 0, 1);
         }
     }
 };
@@ -491,12 +493,23 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
     const uint16_t* A = (const uint16_t*)d->a;
     const uint16_t* W = (const uint16_t*)d->w;
     if (d->m <= 0) return 0;
+    if (d->dtype != CVX_DTYPE_BF16 && d->dtype != CVX_DTYPE_F16) return cvx_fail("gemm: unknown dtype");
+    if (d->dtype == CVX_DTYPE_F16 && d->epilogue != CVX_EPI_BF16 && d->epilogue != CVX_EPI_BF16_GELU && d->epilogue != CVX_EPI_CONVT)
+        return cvx_fail("gemm: fp16 operands are built for the plain / GELU / ConvT epilogues (the segmentation head)");
     switch (d->epilogue) {
         case CVX_EPI_BF16: {
+            if (d->dtype == CVX_DTYPE_F16) {
+                EpiBF16<0, true> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
+                return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            }
             EpiBF16<0> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_BF16_GELU: {
+            if (d->dtype == CVX_DTYPE_F16) {
+                EpiBF16<1, true> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
+                return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            }
             EpiBF16<1> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
@@ -536,6 +549,14 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         }
         case CVX_EPI_CONVT: {
             if (d->cout % 8) return cvx_fail("gemm: ConvT C_out must be a multiple of 8");
+            if (d->dtype == CVX_DTYPE_F16) {  // the head's activations are fp16
+                if (d->act) {
+                    EpiConvT<1, true> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+                    return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+                }
+                EpiConvT<0, true> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+                return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            }
             if (d->act) {
                 EpiConvT<1> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
                 return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
@@ -551,7 +572,7 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
 template <int ACT>
 static int conv3_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
     const long M = (long)d.D * d.H * d.W;
-    EpiBF16<ACT> e{(uint16_t*)d.out, (long)d.cout, d.bias, M, (long)d.cout};
+    EpiBF16<ACT, true> e{(uint16_t*)d.out, (long)d.cout, d.bias, M, (long)d.cout};  // head activations: fp16
     if (d.n_pad % 128 == 0) return launch_conv3<TileCfg<128, 128, 2>>(d, e, st);
     if (d.n_pad % 64 == 0) return launch_conv3<TileCfg<64, 256, 1>>(d, e, st);
     if (d.n_pad % 32 == 0) return launch_conv3<TileCfg<32, 256, 1>>(d, e, st);
@@ -559,7 +580,7 @@ static int conv3_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
     return cvx_fail("conv3d: C_out must be padded to a multiple of 16");
 }
 
-extern "C" int cvx_conv3d_bf16(const cvx_conv3d_desc* d, hipStream_t st) {
+extern "C" int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t st) {
     if (!d) return cvx_fail("conv3d: null descriptor");
     if (d->C % 8) return cvx_fail("conv3d: C_in must be a multiple of 8");
     if (d->k_pad % BK || d->k_pad < 27 * d->C) return cvx_fail("conv3d: K must be 27*C_in padded to a multiple of 64");

@@ -164,8 +164,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a][b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a < 2 ? rlo[a][ks] : rhi[a - 2][ks], lf[b][ks],
-                                                                              acc[a][b0 + b], 0, 0, 0);
+                    acc[a][b0 + b] = mfma16x16x32<epi_is_f16<Epi>::value>(a < 2 ? rlo[a][ks] : rhi[a - 2][ks], lf[b][ks], acc[a][b0 + b]);
         __builtin_amdgcn_s_setprio(0);
     };
     for (int q = 0; q < 4; ++q) issue(q);
@@ -221,7 +220,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a0 + a][b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[a][ks], lf[b][ks], acc[a0 + a][b0 + b], 0, 0, 0);
+                    acc[a0 + a][b0 + b] = mfma16x16x32<epi_is_f16<Epi>::value>(r[a][ks], lf[b][ks], acc[a0 + a][b0 + b]);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -340,7 +339,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
-                    acc[a0 + a][b0 + b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r[a][ks], lf[b][ks], acc[a0 + a][b0 + b], 0, 0, 0);
+                    acc[a0 + a][b0 + b] = mfma16x16x32<epi_is_f16<Epi>::value>(r[a][ks], lf[b][ks], acc[a0 + a][b0 + b]);
         __builtin_amdgcn_s_setprio(0);
     };
     // end of the load segment of phase g: issue half-tile g+AHEAD, then retire (own pieces of) half-tile g+2

@@ -191,7 +191,7 @@ __device__ __forceinline__ void gemm_tile_body(const LoaderR& ldr, const LoaderL
             for (int a = 0; a < FR; ++a)
 #pragma unroll
                 for (int b = 0; b < FL; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rf[a], lf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = mfma16x16x32<epi_is_f16<Epi>::value>(rf[a], lf[b], acc[a][b]);
         }
         __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
     }

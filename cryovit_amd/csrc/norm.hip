@@ -1,5 +1,5 @@
 // Normalisation and layout kernels (HBM-bound): LayerNorm fp32 -> bf16, final LayerNorm + feature layouts,
-// GroupNorm over channels-last bf16 volumes, fp16 [C][D][h][w] -> bf16 channels-last.
+// GroupNorm over channels-last fp16 volumes (the head), fp16 [C][D][h][w] -> fp16 channels-last.
 #include "common.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
@@ -57,11 +57,15 @@ __global__ __launch_bounds__(256) void k_layernorm_bf16(const float* __restrict_
 }
 
 // Final LayerNorm of the patch tokens of `slices` slices, written as
-//   feats_cl  bf16 [slice][p][C]                 (row-major, for the head)
+//   feats_cl  fp16 [slice][p][C]                 (row-major, for the head)
 //   feats_f16 fp16 [C][d_total][npatch] at depth d0+slice   (the reference's `dino_features` layout)
 // A workgroup owns 64 consecutive patch tokens of one slice; the fp16 transposition goes through an LDS tile
 // [256 channels][64 tokens] so global stores are 128-B runs along the token axis.
 constexpr int FN_TOK = 64, FN_CH = 256, FN_PITCH = FN_TOK + 8;  // pitch in halfwords (144 B, 16-B aligned)
+
+// One expression for all three outputs (fp32 tokens, fp16 channels-last, fp16 [C][D][h][w]): the explicit fmaf pins the
+// contraction, so the two fp16 copies hold bit-identical values (the head gives the same result from the file as in HBM).
+__device__ __forceinline__ float ln_out(float x, float mean, float rstd, float w, float b) { return fmaf((x - mean) * rstd, w, b); }
 
 __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                     const float* __restrict__ b, float eps, int ntp, int tok0, int npatch,
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x,
     const int C4 = C >> 2;
     const float* xs = x + ((long)slice * ntp + tok0 + p0) * ldx;
 
-    // phase 1: statistics (and the channels-last bf16 copy) -- one wave per token, 16 tokens per wave
+    // phase 1: statistics (and the channels-last fp16 copy) -- one wave per token, 16 tokens per wave
     for (int t = wave; t < ntile; t += 4) {
         float4 v[LN_MAXJ];
         float mean, rstd;
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x,
                 if (i < C4) {
                     const float4 ww = *(const float4*)(w + 4 * i), bb = *(const float4*)(b + 4 * i);
                     float4 o;
-                    o.x = (v[j].x - mean) * rstd * ww.x + bb.x; o.y = (v[j].y - mean) * rstd * ww.y + bb.y;
-                    o.z = (v[j].z - mean) * rstd * ww.z + bb.z; o.w = (v[j].w - mean) * rstd * ww.w + bb.w;
+                    o.x = ln_out(v[j].x, mean, rstd, ww.x, bb.x); o.y = ln_out(v[j].y, mean, rstd, ww.y, bb.y);
+                    o.z = ln_out(v[j].z, mean, rstd, ww.z, bb.z); o.w = ln_out(v[j].w, mean, rstd, ww.w, bb.w);
                     *(float4*)(orow + 4 * i) = o;
                 }
             }
@@ -103,8 +107,8 @@ __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x,
                 if (i < C4) {
                     const float4 ww = *(const float4*)(w + 4 * i), bb = *(const float4*)(b + 4 * i);
                     uint2 o;
-                    o.x = pack2bf((v[j].x - mean) * rstd * ww.x + bb.x, (v[j].y - mean) * rstd * ww.y + bb.y);
-                    o.y = pack2bf((v[j].z - mean) * rstd * ww.z + bb.z, (v[j].w - mean) * rstd * ww.w + bb.w);
+                    o.x = pack2h(ln_out(v[j].x, mean, rstd, ww.x, bb.x), ln_out(v[j].y, mean, rstd, ww.y, bb.y));
+                    o.y = pack2h(ln_out(v[j].z, mean, rstd, ww.z, bb.z), ln_out(v[j].w, mean, rstd, ww.w, bb.w));
                     *(uint2*)(orow + 4 * i) = o;
                 }
             }
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x,
         if (tid < nch) {
             const float ww = w[c0 + tid], bb = b[c0 + tid];
             for (int t = 0; t < ntile; ++t) {
-                const float val = (xs[(long)t * ldx + c0 + tid] - s_mean[t]) * s_rstd[t] * ww + bb;
-                tile[tid * FN_PITCH + t] = (_Float16)val;
+                const float val = ln_out(xs[(long)t * ldx + c0 + tid], s_mean[t], s_rstd[t], ww, bb);
+                tile[tid * FN_PITCH + t] = __builtin_bit_cast(_Float16, f2h(val));
             }
         }
         __syncthreads();
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x,
     }
 }
 
-// fp16 [C][nvox] -> bf16 [nvox][C]   (HDF5 `dino_features` -> head input), 64x64 LDS transpose tiles
+// fp16 [C][nvox] -> fp16 [nvox][C]   (HDF5 `dino_features` -> head input: a pure transpose, exact), 64x64 LDS tiles
 __global__ __launch_bounds__(256) void k_f16_to_cl(const _Float16* __restrict__ in, uint16_t* __restrict__ out, int C,
                                                    long nvox) {
     __shared__ float tile[64][65];
@@ -157,12 +161,12 @@ __global__ __launch_bounds__(256) void k_f16_to_cl(const _Float16* __restrict__ 
     for (int i = ty; i < 64; i += 4) {
         const long v = v0 + i;
         const int c = c0 + tx;
-        if (v < nvox && c < C) out[v * C + c] = f2bf(tile[tx][i]);
+        if (v < nvox && c < C) out[v * C + c] = f2h(tile[tx][i]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// GroupNorm over x[nvox][C] bf16 (channels-last), G groups of C/G adjacent channels.
+// GroupNorm over x[nvox][C] fp16 (channels-last), G groups of C/G adjacent channels.
 // ---------------------------------------------------------------------------------------------------
 // Statistics are reduced WITHOUT atomics so that the result does not depend on scheduling: lane-private sums -> LDS, summed
 // per channel in thread order -> per-group block partials in global memory -> k_gn_finalize adds the blocks in a fixed order.
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x
         const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float a = bflo(wds[e]), b = bfhi(wds[e]);
+            const float a = hlo(wds[e]), b = hhi(wds[e]);
             s[2 * e] += a; q[2 * e] += a * a;
             s[2 * e + 1] += b; q[2 * e + 1] += b * b;
         }
@@ -240,10 +244,10 @@ __global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x
     for (long v = v0 + vsub; v < v1; v += vstride) {
         const uint4 u = *(const uint4*)(x + v * C + cc * 8);
         uint4 o;
-        o.x = pack2bf(fmaf(bflo(u.x), sc[0], sh[0]), fmaf(bfhi(u.x), sc[1], sh[1]));
-        o.y = pack2bf(fmaf(bflo(u.y), sc[2], sh[2]), fmaf(bfhi(u.y), sc[3], sh[3]));
-        o.z = pack2bf(fmaf(bflo(u.z), sc[4], sh[4]), fmaf(bfhi(u.z), sc[5], sh[5]));
-        o.w = pack2bf(fmaf(bflo(u.w), sc[6], sh[6]), fmaf(bfhi(u.w), sc[7], sh[7]));
+        o.x = pack2h(fmaf(hlo(u.x), sc[0], sh[0]), fmaf(hhi(u.x), sc[1], sh[1]));
+        o.y = pack2h(fmaf(hlo(u.y), sc[2], sh[2]), fmaf(hhi(u.y), sc[3], sh[3]));
+        o.z = pack2h(fmaf(hlo(u.z), sc[4], sh[4]), fmaf(hhi(u.z), sc[5], sh[5]));
+        o.w = pack2h(fmaf(hlo(u.w), sc[6], sh[6]), fmaf(hhi(u.w), sc[7], sh[7]));
         *(uint4*)(out + v * C + cc * 8) = o;
     }
 }
@@ -280,7 +284,7 @@ extern "C" int cvx_features_to_channels_last(const void* feats_f16, void* out_cl
     return cvx_check_launch();
 }
 
-extern "C" int cvx_groupnorm_bf16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
+extern "C" int cvx_groupnorm_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
                                   int G, float eps, hipStream_t st) {
     if (nvox <= 0) return 0;
     const int cpt = C / 8;

@@ -1,6 +1,6 @@
 // Last layer of the segmentation head at full resolution (HBM-bound):
 //   Conv3d(C=8 -> 1, k=3, "same") -> clip(+-5) -> logits / sigmoid -> probs, fused with the masked Dice sums.
-// Input is the channels-last bf16 volume [D][H][W][8] (one voxel = one 16-B load).
+// Input is the channels-last fp16 volume [D][H][W][8] (one voxel = one 16-B load).
 #include "common.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
@@ -41,10 +41,10 @@ __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ 
                     if ((unsigned)xx >= (unsigned)W) continue;
                     const uint4 u = *(const uint4*)(in + (((long)zz * H + yy) * W + xx) * 8);
                     const float* ww = sw + ((kz * 3 + ky) * 3 + kx) * 8;
-                    acc = fmaf(bflo(u.x), ww[0], acc); acc = fmaf(bfhi(u.x), ww[1], acc);
-                    acc = fmaf(bflo(u.y), ww[2], acc); acc = fmaf(bfhi(u.y), ww[3], acc);
-                    acc = fmaf(bflo(u.z), ww[4], acc); acc = fmaf(bfhi(u.z), ww[5], acc);
-                    acc = fmaf(bflo(u.w), ww[6], acc); acc = fmaf(bfhi(u.w), ww[7], acc);
+                    acc = fmaf(hlo(u.x), ww[0], acc); acc = fmaf(hhi(u.x), ww[1], acc);
+                    acc = fmaf(hlo(u.y), ww[2], acc); acc = fmaf(hhi(u.y), ww[3], acc);
+                    acc = fmaf(hlo(u.z), ww[4], acc); acc = fmaf(hhi(u.z), ww[5], acc);
+                    acc = fmaf(hlo(u.w), ww[6], acc); acc = fmaf(hhi(u.w), ww[7], acc);
                 }
             }
         }

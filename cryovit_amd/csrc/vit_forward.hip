@@ -82,6 +82,7 @@ extern "C" int cvx_head_forward(const cvx_head_desc* hd, const cvx_head_ws* ws, 
     {
         cvx_gemm_desc d = gemm_base(CVX_EPI_BF16_GELU, feats_cl, hd->c_in, hd->proj_w, hd->proj_kpad, nv, hd->c0, hd->proj_npad, hd->proj_kpad,
                                     ws->act0, hd->c0, hd->proj_b);
+        d.dtype = CVX_DTYPE_F16;  // the whole head stores fp16 (features, activations, GEMM-side weights)
         CVX_TRY(cvx_gemm_bf16(&d, st));
     }
     const void* act = ws->act0;
@@ -89,21 +90,21 @@ extern "C" int cvx_head_forward(const cvx_head_desc* hd, const cvx_head_ws* ws, 
     for (int i = 0; i < hd->n_blocks; ++i) {
         const cvx_head_block* B = &hd->blocks[i];
         nv = (long)D * H * W;
-        CVX_TRY(cvx_groupnorm_bf16(act, B->gn_w, B->gn_b, ws->gn[i], ws->gn_stats, nv, B->c1, B->groups, 1e-3f, st));
+        CVX_TRY(cvx_groupnorm_f16(act, B->gn_w, B->gn_b, ws->gn[i], ws->gn_stats, nv, B->c1, B->groups, 1e-3f, st));
         {
             cvx_conv3d_desc c = {ws->gn[i], B->conv1_w, B->conv1_b, hd->zero_page, ws->t1[i], B->c1, D, H, W, B->d1, B->c2, B->conv1_npad,
                                  B->conv1_kpad, 1};
-            CVX_TRY(cvx_conv3d_bf16(&c, st));
+            CVX_TRY(cvx_conv3d_f16(&c, st));
         }
         {
             cvx_conv3d_desc c = {ws->t1[i], B->conv2_w, B->conv2_b, hd->zero_page, ws->t2[i], B->c2, D, H, W, B->d2, B->c2, B->conv2_npad,
                                  B->conv2_kpad, 1};
-            CVX_TRY(cvx_conv3d_bf16(&c, st));
+            CVX_TRY(cvx_conv3d_f16(&c, st));
         }
         {
             cvx_gemm_desc d = gemm_base(CVX_EPI_CONVT, ws->t2[i], B->c2, B->convt_w, B->convt_kpad, nv, 4L * B->c3, B->convt_npad, B->convt_kpad,
                                         ws->up[i], B->c3, B->convt_b);
-            d.H = H; d.W = W; d.cout = B->c3; d.act = 1;
+            d.H = H; d.W = W; d.cout = B->c3; d.act = 1; d.dtype = CVX_DTYPE_F16;
             CVX_TRY(cvx_gemm_bf16(&d, st));
         }
         act = ws->up[i];
@@ -112,7 +113,7 @@ extern "C" int cvx_head_forward(const cvx_head_desc* hd, const cvx_head_ws* ws, 
     {
         cvx_conv3d_desc c = {act, hd->out0_w, hd->out0_b, hd->zero_page, ws->mid, hd->c_tail, D, H, W, 1, hd->c_tail, hd->out0_npad,
                              hd->out0_kpad, 1};
-        CVX_TRY(cvx_conv3d_bf16(&c, st));
+        CVX_TRY(cvx_conv3d_f16(&c, st));
     }
     return cvx_conv3_out_fused(ws->mid, hd->out2_w, hd->out2_b, logits, probs, labels, dice, ws->dice_scratch, mask, mask_threshold, D, H,
                                W, st);

@@ -4,11 +4,12 @@ Replaces the ``torch.nn`` calls behind ``CryoVIT.forward_volume`` / ``forward``
 (``/root/reference/src/cryovit/models/cryovit.py:13-49``) and ``SynthesisBlock`` (``:52-83``), plus the masked
 Dice reductions (``models/base_model.py:99-110``, ``models/metrics.py:30-43``).  Layer algebra: SURVEY.md App. B.
 
-Activations are channels-last bf16 volumes ``[D][h][w][C]`` (the ViT's token-major output IS this layout), so
+Activations are channels-last FP16 volumes ``[D][h][w][C]`` (the ViT's token-major output IS this layout; fp16 because the
+reference runs the head under fp16 autocast and bf16 storage costs 10x the logit error -- DESIGN.md s.2), so
 every convolution is a GEMM over contiguous channel vectors:
   Conv3d k=1            -> cvx_gemm_bf16 (GELU epilogue)
-  GroupNorm             -> cvx_groupnorm_bf16 (stats + apply; zero padding must see normalised zeros)
-  Conv3d 3x3x3 dilated  -> cvx_conv3d_bf16 (implicit GEMM, LDS-DMA gather of the 27 taps, GELU epilogue)
+  GroupNorm             -> cvx_groupnorm_f16 (stats + apply; zero padding must see normalised zeros)
+  Conv3d 3x3x3 dilated  -> cvx_conv3d_f16 (implicit GEMM, LDS-DMA gather of the 27 taps, GELU epilogue)
   ConvTranspose (1,2,2) -> cvx_gemm_bf16 with N = 4*C_out and a pixel-shuffle epilogue (GELU)
   Conv3d 8->1 + clip + sigmoid + Dice -> cvx_conv3_out_fused
 """
@@ -41,8 +42,8 @@ def widths_from_state_dict(sd: dict):
 
 
 def _pad2(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
-    out = torch.zeros(n_pad, k_pad, dtype=torch.bfloat16)
-    out[: w.shape[0], : w.shape[1]] = w.to(torch.bfloat16)
+    out = torch.zeros(n_pad, k_pad, dtype=torch.float16)  # GEMM-side weights of the head are stored in fp16
+    out[: w.shape[0], : w.shape[1]] = w.clamp(-65504.0, 65504.0).to(torch.float16)
     return out
 
 
@@ -61,7 +62,7 @@ def _npad(n: int) -> int:
 
 
 def _conv3_weight(w: torch.Tensor) -> torch.Tensor:
-    """[O][C][3][3][3] -> bf16 [n_pad][k_pad], k = ((kz*3+ky)*3+kx)*C + c."""
+    """[O][C][3][3][3] -> fp16 [n_pad][k_pad], k = ((kz*3+ky)*3+kx)*C + c."""
     O, Cin = w.shape[:2]
     return _pad2(w.permute(0, 2, 3, 4, 1).reshape(O, 27 * Cin), _npad(O), round_up(27 * Cin, 64))
 
@@ -156,21 +157,21 @@ class HeadEngine:
         return other
 
     def _buf(self, name: str, rows: int, ch: int) -> torch.Tensor:
-        """bf16 [rows + slack][ch] channels-last buffer (slack rows let K-padded GEMM loads run past the end)."""
+        """fp16 [rows + slack][ch] channels-last buffer (slack rows let K-padded GEMM loads run past the end)."""
         key = (name, rows, ch)
         if key not in self._ws:
-            self._ws[key] = torch.zeros(ops.alloc_rows(rows) * ch + 4096, dtype=torch.bfloat16, device=self.device)
+            self._ws[key] = torch.zeros(ops.alloc_rows(rows) * ch + 4096, dtype=torch.float16, device=self.device)
         return self._ws[key]
 
     def forward(self, feats_cl: torch.Tensor, D: int, h: int, w_: int, labels=None, want_logits=False, want_probs=True,
                 mask_threshold: float | None = None):
-        """feats_cl: bf16 channels-last features [D*h*w (+slack rows), C_in].  Returns dict with
+        """feats_cl: fp16 channels-last features [D*h*w (+slack rows), C_in].  Returns dict with
         ``probs`` / ``logits`` fp32 [D, 16h, 16w], ``dice_sums`` (fp32[3] device tensor) when labels are given and
         ``mask`` uint8 [D, 16h, 16w] = (probs >= mask_threshold) when a threshold is given.  ONE C call: cvx_head_forward."""
         c_in, blocks, _ = self.widths
         ops._dev_check(feats_cl, labels)
-        if feats_cl.dtype != torch.bfloat16 or feats_cl.numel() < ops.alloc_rows(D * h * w_) * c_in:
-            raise ops._lib.CvxError("head: features must be bf16 [rup(D*h*w,256)+256 rows][c_in]")
+        if feats_cl.dtype != torch.float16 or feats_cl.numel() < ops.alloc_rows(D * h * w_) * c_in:
+            raise ops._lib.CvxError("head: features must be fp16 [rup(D*h*w,256)+256 rows][c_in]")
         up = 2 ** len(blocks)
         shape = (D, h * up, w_ * up)
         dev = self.device

@@ -44,9 +44,10 @@ def _dev_check(*ts) -> None:
 
 def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, *, m: int, n: int,
          gamma=None, pos=None, npatch=0, ntp=0, tok0=0, heads=0, kp=0, H=0, W=0, cout=0, act=0, ldc=None) -> None:
-    """C = A W^T with a fused epilogue.  a: bf16 [M_alloc, lda]; w: bf16 [n_pad, k_pad] (packed)."""
+    """C = A W^T with a fused epilogue.  a: bf16 [M_alloc, lda]; w: bf16 [n_pad, k_pad] (packed).  fp16 operands (both a and
+    w) select the fp16 MFMA and fp16 outputs (plain / GELU / ConvT epilogues: the segmentation head)."""
     _dev_check(a, w, out, bias, gamma, pos)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and bias.dtype == torch.float32
+    assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and bias.dtype == torch.float32
     assert a.stride(-1) == 1 and w.is_contiguous() and bias.numel() >= w.shape[0]
     d = GemmDesc()
     d.epilogue = epilogue
@@ -59,6 +60,7 @@ def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bia
     d.pos, d.ldpos = _p(pos), (pos.stride(0) if pos is not None else 0)
     d.npatch, d.ntp, d.tok0, d.heads, d.kp = npatch, ntp, tok0, heads, kp
     d.H, d.W, d.cout, d.act = H, W, cout, act
+    d.dtype = _lib.DTYPE_F16 if a.dtype == torch.float16 else _lib.DTYPE_BF16
     check(_lib.load().cvx_gemm_bf16(C.byref(d), _stream()), "cvx_gemm_bf16")
 
 
@@ -69,7 +71,7 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tens
     d.in_, d.w, d.bias, d.zero_page, d.out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), zero_page.data_ptr(), out.data_ptr()
     d.C, d.D, d.H, d.W, d.dil, d.cout = Cin, D, H, W, dil, cout
     d.n_pad, d.k_pad, d.act = w.shape[0], w.shape[1], act
-    check(_lib.load().cvx_conv3d_bf16(C.byref(d), _stream()), "cvx_conv3d_bf16")
+    check(_lib.load().cvx_conv3d_f16(C.byref(d), _stream()), "cvx_conv3d_f16")
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, rows: int, Cdim: int, eps: float) -> None:
@@ -132,8 +134,8 @@ def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tens
     _dev_check(x, w, b, out, stats)
     if stats.dtype != torch.float32 or stats.numel() < gn_stats_size(G):
         raise _lib.CvxError(f"groupnorm: stats must be fp32 with >= {gn_stats_size(G)} elements (2*G*(1+CVX_GN_BLOCKS))")
-    check(_lib.load().cvx_groupnorm_bf16(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(), nvox, Cdim,
-                                         G, eps, _stream()), "cvx_groupnorm_bf16")
+    check(_lib.load().cvx_groupnorm_f16(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(), nvox, Cdim,
+                                         G, eps, _stream()), "cvx_groupnorm_f16")
 
 
 _dice_scratch = {}

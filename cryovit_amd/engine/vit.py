@@ -242,7 +242,7 @@ class VitEngine:
     # ---- forward ----------------------------------------------------------------------------------------------------
     def features(self, slices: torch.Tensor, feats_f16=None, d_total: int = 0, d0: int = 0, feats_cl=None) -> None:
         """slices: device uint8/float32 [b,H,W] (raw tomogram slices).  Writes
-        feats_f16 fp16 [C, d_total, hp, wp] at depth d0..d0+b-1 and/or feats_cl bf16 [b, hp, wp, C]."""
+        feats_f16 fp16 [C, d_total, hp, wp] at depth d0..d0+b-1 and/or feats_cl fp16 [b, hp, wp, C]."""
         b, H, W = slices.shape
         hp, wp = math.ceil(H / 16), math.ceil(W / 16)
         ws = self._workspace(b, hp, wp)

@@ -74,12 +74,12 @@ class CryoVIT(nn.Module):
         outs = []
         for xb in x:
             C, D, h, w = xb.shape
-            cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.bfloat16, device=self._device)
+            cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.float16, device=self._device)
             src = xb.to(self._device)
             if src.dtype == torch.float16 and src.is_contiguous():
                 ops.features_to_channels_last(src, cl)
             else:
-                cl[: D * h * w] = src.permute(1, 2, 3, 0).reshape(-1, C).to(torch.bfloat16)
+                cl[: D * h * w] = src.permute(1, 2, 3, 0).reshape(-1, C).to(torch.float16)
             outs.append(self.engine().forward(cl, D, h, w, want_logits=True, want_probs=False)["logits"])
         return torch.stack(outs).unsqueeze(1)
 
@@ -96,14 +96,14 @@ class CryoVIT(nn.Module):
         outs = []
         for xb in batch.tomo_batch:  # [D,C,h,w]
             D, C, h, w = xb.shape
-            cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.bfloat16, device=self._device)
-            cl[: D * h * w] = xb.to(self._device).permute(0, 2, 3, 1).reshape(-1, C).to(torch.bfloat16)
+            cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.float16, device=self._device)
+            cl[: D * h * w] = xb.to(self._device).permute(0, 2, 3, 1).reshape(-1, C).to(torch.float16)
             outs.append(self.engine().forward(cl, D, h, w, want_probs=False, mask_threshold=threshold)["mask"])
         return outs
 
     @torch.inference_mode()
     def predict_with_dice(self, feats_cl: Tensor, D: int, h: int, w: int, labels: Tensor | None):
-        """Fused inference used by the end-to-end runner: channels-last bf16 features straight from the encoder ->
+        """Fused inference used by the end-to-end runner: channels-last fp16 features straight from the encoder ->
         probabilities and (with labels) the masked Dice of ``_masked_predict`` + ``DiceMetric``."""
         out = self.engine().forward(feats_cl, D, h, w, labels=None if labels is None else labels.to(self._device, torch.int8).contiguous())
         dice = None

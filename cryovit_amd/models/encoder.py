@@ -48,7 +48,7 @@ class DinoEncoder:
         hp, wp, _, _, _ = self.engine.geometry(H, W)
         C = self.cfg.dim
         f16 = torch.empty(C, D, hp, wp, dtype=torch.float16, device=self.device) if want_f16 else None
-        cl = torch.zeros(ops.alloc_rows(D * hp * wp), C, dtype=torch.bfloat16, device=self.device) if want_cl else None
+        cl = torch.zeros(ops.alloc_rows(D * hp * wp), C, dtype=torch.float16, device=self.device) if want_cl else None
         for d0 in range(0, D, batch_size):
             b = min(batch_size, D - d0)
             self.engine.features(vol[d0 : d0 + b], feats_f16=f16, d_total=D, d0=d0,

@@ -26,7 +26,7 @@ from cryovit_amd.run.sharding import gather_rows, shard_records, world_info
 def segment_tomogram(path: Path, head, label_key: str | None, encoder=None, batch_size: int = 128, input_key: str = "dino_features"):
     """One tomogram file -> (probs fp32 [D,H,W] device tensor, dice | None, labels | None).
 
-    With ``encoder`` the features are computed from ``data`` and handed to the head in channels-last bf16 without leaving
+    With ``encoder`` the features are computed from ``data`` and handed to the head in channels-last fp16 without leaving
     HBM; otherwise ``input_key`` (float16 [C,D,h,w], the feature stage's output) is read from the file."""
     labels = None
     if label_key is not None:
@@ -40,11 +40,11 @@ def segment_tomogram(path: Path, head, label_key: str | None, encoder=None, batc
     else:
         feats = torch.from_numpy(io.read_dataset(path, input_key)).to(head._device)
         C, D, hp, wp = feats.shape
-        cl = torch.zeros(ops.alloc_rows(D * hp * wp), C, dtype=torch.bfloat16, device=head._device)
+        cl = torch.zeros(ops.alloc_rows(D * hp * wp), C, dtype=torch.float16, device=head._device)
         if feats.dtype == torch.float16:
             ops.features_to_channels_last(feats.contiguous(), cl)
         else:
-            cl[: D * hp * wp] = feats.permute(1, 2, 3, 0).reshape(-1, C).to(torch.bfloat16)
+            cl[: D * hp * wp] = feats.permute(1, 2, 3, 0).reshape(-1, C).to(torch.float16)
     probs, dice = head.predict_with_dice(cl, D, hp, wp, labels)
     return probs, dice, labels
 

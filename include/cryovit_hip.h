@@ -9,7 +9,7 @@
  *                     replace   model.forward_features(vec)["x_norm_patchtokens"] + reshape/permute/half
  *                               src/cryovit/run/dino_features.py:53-61  and the CPU bicubic resize of
  *                               src/cryovit/datasets/vit_dataset.py:117-123 (fused into the first kernel)
- *   the head launch list (cvx_gemm_bf16, cvx_groupnorm_bf16, cvx_conv3d_bf16, cvx_conv3_out_fused)
+ *   cvx_head_forward (= cvx_gemm_bf16 with fp16 operands, cvx_groupnorm_f16, cvx_conv3d_f16, cvx_conv3_out_fused)
  *                     replaces  CryoVIT.forward_volume + sigmoid          src/cryovit/models/cryovit.py:36-49
  *                               and the masked Dice reductions            src/cryovit/models/base_model.py:99-110,
  *                                                                         src/cryovit/models/metrics.py:30-43
@@ -63,6 +63,8 @@ enum cvx_epilogue {
     CVX_EPI_CONVT = 6      /* out bf16 [D][2H][2W][cout] pixel-shuffle of N = 4*cout, optional GELU   */
 };
 
+enum { CVX_DTYPE_BF16 = 0, CVX_DTYPE_F16 = 1 };
+
 typedef struct cvx_gemm_desc {
     int epilogue;
     const void* a; long lda;   /* bf16 [M_alloc][lda]  */
@@ -75,6 +77,8 @@ typedef struct cvx_gemm_desc {
     int npatch, ntp, tok0;     /* PATCH: patches per slice, padded tokens per slice, first patch token */
     int heads, kp;             /* VT: heads, padded key count (multiple of 64) */
     int H, W, cout, act;       /* CONVT: input plane size, C_out, act (0 none / 1 GELU) */
+    int dtype;                 /* CVX_DTYPE_BF16 (0, default): bf16 operands / 16-bit outputs; CVX_DTYPE_F16: fp16 operands
+                                  and outputs (BF16, BF16_GELU and CONVT epilogues only: the segmentation head) */
 } cvx_gemm_desc;
 
 int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t stream);
@@ -84,15 +88,17 @@ int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t stream);
 int cvx_set_gemm_event_hook(int epilogue, void** start_events, void** stop_events, int capacity);
 int cvx_get_gemm_event_count(void);
 
-/* Dilated 3x3x3 "same" convolution, dilation (dil,1,1), channels-last bf16 volume in[D][H][W][C] ->
- * out[D][H][W][cout] = act(conv + bias), as an implicit GEMM (K = tap*C + c).  w is bf16 [n_pad][k_pad] with
+/* Dilated 3x3x3 "same" convolution, dilation (dil,1,1), channels-last FP16 volume in[D][H][W][C] ->
+ * out[D][H][W][cout] fp16 = act(conv + bias), as an implicit GEMM (K = tap*C + c) on v_mfma_f32_16x16x32_f16 (the head
+ * stores fp16: the reference runs it under fp16 autocast, and fp16 storage keeps the logits within 1e-2 of the fp32 CPU
+ * path where bf16 storage costs 0.2 -- DESIGN.md s.2).  w is fp16 [n_pad][k_pad] with
  * k = ((kz*3+ky)*3+kx)*C + c.  zero_page: >= 16 zero bytes on the device (source of padded taps).
  * Replaces nn.Conv3d(c1,c2,3,padding="same",dilation=(d,1,1)) -- cryovit/models/cryovit.py:70-73,30-33. */
 typedef struct cvx_conv3d_desc {
     const void* in; const void* w; const float* bias; const void* zero_page; void* out;
     int C, D, H, W, dil, cout, n_pad, k_pad, act;
 } cvx_conv3d_desc;
-int cvx_conv3d_bf16(const cvx_conv3d_desc* d, hipStream_t stream);
+int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t stream);
 
 /* LayerNorm over the last dim of an fp32 token stream -> bf16 (GEMM operand).  eps inside the sqrt.
  * x fp32 [rows][ldx], out bf16 [rows][ldo].  Replaces nn.LayerNorm(C, eps=1e-6) in the hub ViT blocks. */
@@ -124,7 +130,7 @@ int cvx_init_tokens(float* x, long ldx, const float* cls_pos0, const float* reg,
 
 /* Final LayerNorm + drop cls/registers + layout transform (run/dino_features.py:58-61):
  *   feats_f16  (nullable) fp16 [C][d_total][hp][wp], slices written at depth d0..d0+slices-1
- *   feats_cl   (nullable) bf16 [slices][hp][wp][C]   channels-last copy for the segmentation head
+ *   feats_cl   (nullable) fp16 [slices][hp][wp][C]   channels-last copy for the segmentation head (same rounding as feats_f16)
  *   tokens_f32 (nullable) fp32 [slices][hp*wp][C]    "x_norm_patchtokens" of the encoder protocol */
 int cvx_final_norm_features(const float* x, long ldx, const float* w, const float* b, float eps, int slices,
                             int ntp, int tok0, int hp, int wp, int C, void* feats_f16, long d_total, long d0,
@@ -135,23 +141,23 @@ int cvx_final_norm_features(const float* x, long ldx, const float* w, const floa
  * k = c*196 + py*14 + px (the flattening of Conv2d(3,C,14,14).weight), zero padded to k_pad >= 588. */
 int cvx_im2col_patches(const float* x, int b, int Hi, int Wi, void* out, int k_pad, hipStream_t stream);
 
-/* fp16 [C][D][h][w] (the HDF5 `dino_features` layout) -> bf16 channels-last [D][h][w][C] */
+/* fp16 [C][D][h][w] (the HDF5 `dino_features` layout) -> fp16 channels-last [D][h][w][C] (a transpose: exact) */
 int cvx_features_to_channels_last(const void* feats_f16, void* out_cl, int C, long nvox, hipStream_t stream);
 
-/* GroupNorm over a channels-last bf16 volume x[nvox][C], G groups (<= 128), biased variance, eps inside sqrt
+/* GroupNorm over a channels-last fp16 volume x[nvox][C], G groups (<= 128), biased variance, eps inside sqrt
  * (nn.GroupNorm(G, C, eps=1e-3) -- cryovit.py:69).  Three launches: per-block partial sums, fixed-order reduction (no
- * atomics: results are bitwise reproducible), apply -> bf16 out.  stats: fp32 scratch of 2*G*(1 + CVX_GN_BLOCKS) floats
+ * atomics: results are bitwise reproducible), apply -> fp16 out.  stats: fp32 scratch of 2*G*(1 + CVX_GN_BLOCKS) floats
  * (stats[0..2G) = sum | sum of squares per group after the call). */
 #define CVX_GN_BLOCKS 1024
-int cvx_groupnorm_bf16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
+int cvx_groupnorm_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
                        int G, float eps, hipStream_t stream);
 
-/* Last layer of the head at full resolution, channels-last bf16 in[D][H][W][8]:
+/* Last layer of the head at full resolution, channels-last fp16 in[D][H][W][8]:
  *   conv3x3x3(8->1, w fp32 [27][8] tap-major) + bias, clip(+-5) -> logits fp32 (nullable), sigmoid -> probs fp32
  *   (nullable), and masked Dice partial sums (labels int8 nullable; dice must be zeroed by the caller):
  *   dice[0] += sum(y*p_hat), dice[1] += sum(y), dice[2] += sum(p_hat) over labels > -1, p_hat = (p >= 0.5).
  * Replaces output_layer.2 + clip + sigmoid (cryovit.py:33,39,49) and the reductions of
- * base_model.py:99-110 / metrics.py:36-41.  (output_layer.0 + GELU runs through cvx_conv3d_bf16.)
+ * base_model.py:99-110 / metrics.py:36-41.  (output_layer.0 + GELU runs through cvx_conv3d_f16.)
  * scratch: >= 3*CVX_DICE_BLOCKS floats (per-block partial sums, reduced in a fixed order: reproducible).
  * mask (nullable): uint8 [D][H][W] = (p >= mask_threshold), the binary segmentation PredictionWriter stores
  * (src/cryovit/models/callbacks.py:100-102), written here so that only 1 byte per voxel leaves the GPU. */
@@ -246,14 +252,14 @@ int cvx_vit_encode(const cvx_vit_desc* vit, const cvx_vit_ws* ws, int b, int hp,
  * 1e-3), dilated Conv3d + GELU, dilated Conv3d + GELU, ConvTranspose3d (1,2,2) + GELU }, Conv3d(8,8,3) + GELU, Conv3d(8,1,3),
  * clip(+-5), sigmoid, masked Dice sums and the thresholded uint8 segmentation.  Replaces CryoVIT.forward_volume / forward
  * (src/cryovit/models/cryovit.py:36-49), the reductions of base_model.py:99-110 / metrics.py:36-41 and PredictionWriter's
- * threshold (callbacks.py:100-102).  Weights packed as documented for cvx_gemm_bf16 / cvx_conv3d_bf16.
+ * threshold (callbacks.py:100-102).  Weights packed as documented for cvx_gemm_bf16 / cvx_conv3d_f16, in FP16.
  * ------------------------------------------------------------------------------------------------- */
 typedef struct cvx_head_block {
     int c1, c2, c3, d1, d2, groups;           /* SynthesisBlock(c1, c2, c3, d1, d2); groups = max(8, c1/8) */
     const float *gn_w, *gn_b;                 /* fp32 [c1] */
-    const void* conv1_w; const float* conv1_b; int conv1_npad, conv1_kpad;   /* bf16 [npad][rup(27*c1,64)] */
-    const void* conv2_w; const float* conv2_b; int conv2_npad, conv2_kpad;   /* bf16 [npad][rup(27*c2,64)] */
-    const void* convt_w; const float* convt_b; int convt_npad, convt_kpad;   /* bf16 [npad(4*c3)][rup(c2,64)], row (i*2+j)*c3 + o */
+    const void* conv1_w; const float* conv1_b; int conv1_npad, conv1_kpad;   /* fp16 [npad][rup(27*c1,64)] */
+    const void* conv2_w; const float* conv2_b; int conv2_npad, conv2_kpad;   /* fp16 [npad][rup(27*c2,64)] */
+    const void* convt_w; const float* convt_b; int convt_npad, convt_kpad;   /* fp16 [npad(4*c3)][rup(c2,64)], row (i*2+j)*c3 + o */
 } cvx_head_block;
 
 typedef struct cvx_head_desc {
@@ -266,7 +272,7 @@ typedef struct cvx_head_desc {
 } cvx_head_desc;
 
 #define CVX_HEAD_MAX_BLOCKS 8
-typedef struct cvx_head_ws {                  /* device workspaces, bf16 channels-last, rows = rup(voxels,256)+256 (+2048 elements) */
+typedef struct cvx_head_ws {                  /* device workspaces, fp16 channels-last, rows = rup(voxels,256)+256 (+2048 elements) */
     void* act0;                               /* [D*h*w rows][c0] */
     void* gn[CVX_HEAD_MAX_BLOCKS];            /* block i input resolution rows x c1 */
     void* t1[CVX_HEAD_MAX_BLOCKS];            /* rows x c2 */
@@ -277,7 +283,7 @@ typedef struct cvx_head_ws {                  /* device workspaces, bf16 channel
     float* dice_scratch;                      /* fp32 [3*CVX_DICE_BLOCKS] (only read when labels != NULL) */
 } cvx_head_ws;
 
-/* feats_cl: bf16 channels-last features [D*h*w (+pad rows)][c_in] (cvx_vit_encode's feats_cl or
+/* feats_cl: FP16 channels-last features [D*h*w (+pad rows)][c_in] (cvx_vit_encode's feats_cl or
  * cvx_features_to_channels_last).  Outputs at 2^n_blocks x the in-plane resolution, all nullable: logits / probs fp32,
  * dice fp32[3] (+=, needs labels int8), mask uint8 (probs >= mask_threshold). */
 int cvx_head_forward(const cvx_head_desc* head, const cvx_head_ws* ws, const void* feats_cl, int D, int h, int w, float* logits,

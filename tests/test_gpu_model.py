@@ -1,11 +1,13 @@
 """Model-level parity on the GPU: HIP path (through the C ABI) vs the CPU oracle / committed golden fixtures.
 
-Stated tolerances of the bf16 HIP path against the fp32 CPU path:
+Stated tolerances of the HIP path (bf16 ViT, fp16 head) against the fp32 CPU path:
   x_norm_patchtokens (unit-scale LayerNorm outputs): max abs <= 1e-1, mean abs <= 1e-2; fp16 store adds <= 2e-3
-  head logits (range [-5,5], std ~1): max abs <= 2.5e-1, mean abs <= 2e-2 -- this is the cost of storing the 14
-    inter-layer activations in bf16 (8 significand bits); a CPU emulation of bf16 STORAGE with exact arithmetic
-    (oracle.head.forward_volume_bf16_storage) shows the same 0.21 max / 0.014 mean on the narrow fixture, and the
-    HIP path must match THAT emulation to atol 3e-2 (kernel-correctness bar)
+  head logits (range [-5,5], std ~1) on identical input features: max abs <= 5e-2, mean abs <= 5e-3 (the bound SURVEY
+    App. E proposes).  The head stores its 14 inter-layer activations in FP16 like the reference's fp16 autocast: a CPU
+    emulation with exact arithmetic (oracle.head.forward_volume_16bit_storage) puts fp16 storage at ~0.02 max / 0.002 mean
+    on the narrow fixture where bf16 storage costs 0.21 / 0.014, and the HIP path must match THAT emulation to max 3e-2 /
+    mean 2e-3 (kernel-correctness bar; measured 0.019 / 0.0012)
+  end to end (head fed with the GPU's own ViT features): logits max abs <= 2.5e-1, mean abs <= 2e-2
   |dDice| <= 1e-3
 """
 
@@ -134,16 +136,19 @@ def test_head_narrow_golden(gpu, gold):
     eng = HeadEngine(head.state_dict(), gpu)
     feats = torch.from_numpy(g["feats"])  # [C,D,h,w]
     C, D, h, w = feats.shape
-    cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.bfloat16, device=gpu)
-    cl[: D * h * w] = feats.permute(1, 2, 3, 0).reshape(-1, C).to(torch.bfloat16).to(gpu)
+    cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.float16, device=gpu)
+    cl[: D * h * w] = feats.permute(1, 2, 3, 0).reshape(-1, C).to(torch.float16).to(gpu)
     labels = torch.from_numpy(g["labels"]).to(gpu)
     out = eng.forward(cl, D, h, w, labels=labels, want_logits=True)
     ref = torch.from_numpy(g["logits"])
     got = out["logits"].cpu()
-    emu = oh.forward_volume_bf16_storage(head, feats.unsqueeze(0))[0, 0]
-    assert float((got - emu).abs().max()) <= 3e-2, float((got - emu).abs().max())  # kernels vs exact-arithmetic bf16 storage
+    emu = oh.forward_volume_16bit_storage(head, feats.unsqueeze(0), torch.float16)[0, 0]
+    e_emu = (got - emu).abs()  # kernels vs exact-arithmetic fp16 storage: 1-ulp rounding flips of single activations
+    assert float(e_emu.max()) <= 3e-2 and float(e_emu.mean()) <= 2e-3, (float(e_emu.max()), float(e_emu.mean()))
     err = (got - ref).abs()
-    assert float(err.max()) <= 2.5e-1 and float(err.mean()) <= 2e-2, (float(err.max()), float(err.mean()))  # vs fp32 CPU
+    assert float(err.max()) <= 5e-2 and float(err.mean()) <= 5e-3, (float(err.max()), float(err.mean()))  # vs fp32 CPU
+    e_bf = (oh.forward_volume_bf16_storage(head, feats.unsqueeze(0))[0, 0] - ref).abs()
+    assert float(e_bf.max()) > 3 * float(err.max())  # why the head is not bf16: that storage alone is several times worse
     i, sy, sp = out["dice_sums"].cpu().tolist()
     dice = 2 * i / (sy + sp + 1e-3)
     near = int(((ref.abs() < 5e-2) & (torch.from_numpy(g["labels"]) > -1)).sum())
@@ -166,25 +171,25 @@ def test_synthesis_block_golden(gpu, gold):
     C, D, H, W = x.shape
     nv = D * H * W
     t = lambda k: torch.from_numpy(g[k])  # noqa: E731
-    xin = x.permute(1, 2, 3, 0).reshape(nv, C).contiguous().to(torch.bfloat16).to(gpu)
+    xin = x.permute(1, 2, 3, 0).reshape(nv, C).contiguous().to(torch.float16).to(gpu)
     zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
     stats = torch.zeros(ops.gn_stats_size(8), device=gpu)
     gn = torch.zeros_like(xin)
     ops.groupnorm(xin, t("layers_0_weight").to(gpu), t("layers_0_bias").to(gpu), gn, stats, nvox=nv, Cdim=32, G=8, eps=1e-3)
-    t1 = torch.zeros(nv, 16, dtype=torch.bfloat16, device=gpu)
+    t1 = torch.zeros(nv, 16, dtype=torch.float16, device=gpu)
     ops.conv3d(gn, _conv3_weight(t("layers_1_weight")).to(gpu), _pad1(t("layers_1_bias"), 16).to(gpu), t1, zero, Cin=32, D=D, H=H, W=W,
                dil=2, cout=16, act=1)
-    t2 = torch.zeros(ops.alloc_rows(nv) * 16 + 4096, dtype=torch.bfloat16, device=gpu)
+    t2 = torch.zeros(ops.alloc_rows(nv) * 16 + 4096, dtype=torch.float16, device=gpu)
     ops.conv3d(t1, _conv3_weight(t("layers_3_weight")).to(gpu), _pad1(t("layers_3_bias"), 16).to(gpu), t2, zero, Cin=16, D=D, H=H, W=W,
                dil=1, cout=16, act=1)
     wt = t("layers_5_weight")
     wg = wt[:, :, 0].permute(2, 3, 1, 0).reshape(32, 16)
-    out = torch.zeros(D, 2 * H, 2 * W, 8, dtype=torch.bfloat16, device=gpu)
+    out = torch.zeros(D, 2 * H, 2 * W, 8, dtype=torch.float16, device=gpu)
     ops.gemm(EPI_CONVT, torch.as_strided(t2, (ops.alloc_rows(nv), 16), (16, 1)), _pad2(wg, _npad(32), 64).to(gpu), out,
              _pad1(t("layers_5_bias").repeat(4), _npad(32)).to(gpu), m=nv, n=32, H=H, W=W, cout=8, act=1, ldc=8)
     got = out.float().cpu().permute(3, 0, 1, 2)
-    # activations here reach |y| ~ 27 (weights N(0,0.2)): bf16 storage of 3 intermediate layers -> rtol 2e-2 of scale
-    assert torch.allclose(got, y, atol=2e-1, rtol=2e-2), float((got - y).abs().max())
+    # activations here reach |y| ~ 27 (weights N(0,0.2)): fp16 storage of 3 intermediate layers -> rtol 3e-3 of scale
+    assert torch.allclose(got, y, atol=3e-2, rtol=3e-3), float((got - y).abs().max())
 
 
 def test_e2e_tiny_golden(gpu, gold):
@@ -206,7 +211,7 @@ def test_e2e_tiny_golden(gpu, gold):
     hp, wp = math.ceil(H / 16), math.ceil(W / 16)
     C = ocfg.dim
     f16 = torch.zeros(C, D, hp, wp, dtype=torch.float16, device=gpu)
-    cl = torch.zeros(ops.alloc_rows(D * hp * wp), C, dtype=torch.bfloat16, device=gpu)
+    cl = torch.zeros(ops.alloc_rows(D * hp * wp), C, dtype=torch.float16, device=gpu)
     for d0 in range(0, D, 3):
         b = min(3, D - d0)
         vit.features(vol[d0 : d0 + b], feats_f16=f16, d_total=D, d0=d0, feats_cl=cl[d0 * hp * wp :])
@@ -269,7 +274,7 @@ def test_full_size_properties(gpu):
     hp = wp = 32
     f_a = torch.zeros(1536, D, hp, wp, dtype=torch.float16, device=gpu)
     f_b = torch.zeros_like(f_a)
-    cl = torch.zeros(ops.alloc_rows(D * hp * wp), 1536, dtype=torch.bfloat16, device=gpu)
+    cl = torch.zeros(ops.alloc_rows(D * hp * wp), 1536, dtype=torch.float16, device=gpu)
     vit.features(vol, feats_f16=f_a, d_total=D, d0=0, feats_cl=cl)
     vit.features(vol, feats_f16=f_b, d_total=D, d0=0)
     assert torch.equal(f_a, f_b), "ViT path is not deterministic"
@@ -311,13 +316,13 @@ def test_head_full_width_midsize_vs_oracle(gpu):
     with torch.inference_mode():
         ref = head.forward_volume(feats.float().unsqueeze(0))[0, 0]
     eng = HeadEngine(head.state_dict(), gpu)
-    cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.bfloat16, device=gpu)
+    cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.float16, device=gpu)
     ops.features_to_channels_last(feats.to(gpu), cl)
     labels = torch.from_numpy(synth_labels(D, 16 * h, 16 * w, seed=4))
     out = eng.forward(cl, D, h, w, labels=labels.to(gpu), want_logits=True)
     got = out["logits"].cpu()
     err = (got - ref).abs()
-    assert float(err.max()) <= 2.5e-1 and float(err.mean()) <= 2e-2, (float(err.max()), float(err.mean()))
+    assert float(err.max()) <= 5e-2 and float(err.mean()) <= 5e-3, (float(err.max()), float(err.mean()))  # fp16 head vs fp32 CPU
     i, sy, sp = out["dice_sums"].cpu().tolist()
     dice = 2 * i / (sy + sp + 1e-3)
     want = od.dice_metric(torch.sigmoid(ref), labels.float())

@@ -15,6 +15,10 @@ def bf(t):
     return t.to(torch.bfloat16)
 
 
+def hf(t):  # the segmentation head stores fp16 (11 significand bits: rel. 2^-12 per rounding)
+    return t.to(torch.float16)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
@@ -50,6 +54,49 @@ def test_gemm_bf16(gpu, M, N, K, gelu):
     # bf16 output rounding (2^-9 relative) + fp32 accumulation order
     assert torch.allclose(got, ref, atol=2e-2, rtol=1e-2), float((got - ref).abs().max())
     assert torch.all(out[M:].float() == 7.0), "rows beyond M were written"
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (257, 40, 64), (4096, 1024, 1536)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_fp16_operands(gpu, M, N, K, gelu):
+    """The head's GEMMs: fp16 operands on v_mfma_f32_16x16x32_f16, fp16 output (the last shape takes the 256x256 pipeline).
+    fp16 output rounding is 2^-12 relative: the tolerance is 8x tighter than the bf16 test above."""
+    from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _npad
+
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K**-0.5), rnd(N, seed=3)
+    n_pad, k_pad = _npad(N), ops.round_up(K, 64)
+    A = torch.zeros(ops.alloc_rows(M), k_pad, dtype=torch.float16)
+    A[:M, :K] = hf(a)
+    Wd = torch.zeros(n_pad, k_pad, dtype=torch.float16)
+    Wd[:N, :K] = hf(w)
+    out = torch.full((ops.alloc_rows(M), N), 7.0, dtype=torch.float16, device=gpu)
+    ops.gemm(EPI_BF16_GELU if gelu else EPI_BF16, A.to(gpu), Wd.to(gpu), out, padded_f32(b, n_pad, gpu), m=M, n=N)
+    ref = hf(a).float() @ hf(w).float().T + b
+    ref = F.gelu(ref) if gelu else ref
+    got = out[:M].float().cpu()
+    assert torch.allclose(got, ref, atol=3e-3, rtol=2e-3), float((got - ref).abs().max())
+    assert torch.all(out[M:].float() == 7.0), "rows beyond M were written"
+
+
+def test_gemm_fp16_saturates_instead_of_inf(gpu):
+    """fp16 stores clamp to the largest finite half (65504): an activation spike cannot turn into inf / NaN downstream."""
+    from cryovit_amd._lib import EPI_BF16
+    from cryovit_amd.engine import ops
+
+    M, N, K = 64, 64, 64
+    A = torch.full((ops.alloc_rows(M), K), 200.0, dtype=torch.float16, device=gpu)
+    Wd = torch.full((N, K), 100.0, dtype=torch.float16, device=gpu)
+    Wd[1::2] *= -1
+    out = torch.zeros(ops.alloc_rows(M), N, dtype=torch.float16, device=gpu)
+    ops.gemm(EPI_BF16, A, Wd, out, torch.zeros(N, device=gpu), m=M, n=N)  # +-1.28e6 before rounding
+    got = out[:M].float().cpu()
+    assert torch.all(got[:, 0::2] == 65504.0) and torch.all(got[:, 1::2] == -65504.0)
+    with pytest.raises(Exception, match="fp16 operands are built for"):
+        from cryovit_amd._lib import EPI_RESID
+
+        ops.gemm(EPI_RESID, A, Wd, torch.zeros(ops.alloc_rows(M), N, device=gpu), torch.zeros(N, device=gpu), gamma=torch.ones(N, device=gpu), m=M, n=N)
 
 
 def test_gemm_swiglu(gpu):
@@ -228,7 +275,7 @@ def test_final_norm_and_k9_layout(gpu):
     w, bb = rnd(C, seed=32) + 1, rnd(C, seed=33)
     d_total, d0 = 5, 1
     f16 = torch.full((C, d_total, hp, wp), -9.0, dtype=torch.float16, device=gpu)
-    cl = torch.zeros(b, hp, wp, C, dtype=torch.bfloat16, device=gpu)
+    cl = torch.zeros(b, hp, wp, C, dtype=torch.float16, device=gpu)
     ops.final_norm_features(x.reshape(-1, C).to(gpu), w.to(gpu), bb.to(gpu), 1e-6, slices=b, ntp=ntp, tok0=1 + n_reg, hp=hp, wp=wp,
                             Cdim=C, feats_f16=f16, d_total=d_total, d0=d0, feats_cl=cl)
     ref = F.layer_norm(x[:, 1 + n_reg : nt], (C,), w, bb, 1e-6)  # [b, npatch, C]
@@ -236,7 +283,9 @@ def test_final_norm_and_k9_layout(gpu):
     got = f16.float().cpu()
     assert torch.allclose(got[:, d0 : d0 + b], ref_k9, atol=3e-3, rtol=2e-3)  # fp16 store
     assert torch.all(got[:, :d0] == -9.0) and torch.all(got[:, d0 + b :] == -9.0)
-    assert torch.allclose(cl.float().cpu().reshape(b, npatch, C), ref, atol=2e-2, rtol=1e-2)
+    assert torch.allclose(cl.float().cpu().reshape(b, npatch, C), ref, atol=3e-3, rtol=2e-3)  # fp16 channels-last copy
+    # the two fp16 copies (file layout / head layout) hold bit-identical values: the head sees the same input either way
+    assert torch.equal(cl.cpu().reshape(b, hp, wp, C).permute(3, 0, 1, 2), f16[:, d0 : d0 + b].cpu())
 
 
 def test_features_to_channels_last(gpu):
@@ -244,10 +293,9 @@ def test_features_to_channels_last(gpu):
 
     C, D, h, w = 136, 3, 5, 7
     f = rnd(C, D, h, w, seed=34).half()
-    out = torch.zeros(D * h * w, C, dtype=torch.bfloat16, device=gpu)
+    out = torch.zeros(D * h * w, C, dtype=torch.float16, device=gpu)
     ops.features_to_channels_last(f.to(gpu), out)
-    ref = bf(f.float().reshape(C, -1).T)
-    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(out.cpu(), f.reshape(C, -1).T)  # a transpose of the fp16 file contents: exact
 
 
 @pytest.mark.parametrize("C,G", [(128, 16), (32, 8), (8, 8), (1024, 128)])
@@ -255,23 +303,23 @@ def test_groupnorm(gpu, C, G):
     from cryovit_amd.engine import ops
 
     D, H, W = 5, 6, 7
-    x = bf(rnd(D, H, W, C, seed=35) * 1.5 + 0.4)
+    x = hf(rnd(D, H, W, C, seed=35) * 1.5 + 0.4)
     w, b = rnd(C, seed=36) + 1, rnd(C, seed=37)
     out = torch.zeros_like(x, device=gpu)
     stats = torch.zeros(ops.gn_stats_size(G), device=gpu)
     ops.groupnorm(x.to(gpu), w.to(gpu), b.to(gpu), out, stats, nvox=D * H * W, Cdim=C, G=G, eps=1e-3)
     ref = F.group_norm(x.float().permute(3, 0, 1, 2).unsqueeze(0), G, w, b, 1e-3)[0].permute(1, 2, 3, 0)
-    assert torch.allclose(out.float().cpu(), ref, atol=3e-2, rtol=1e-2), float((out.float().cpu() - ref).abs().max())
+    assert torch.allclose(out.float().cpu(), ref, atol=4e-3, rtol=2e-3), float((out.float().cpu() - ref).abs().max())
 
 
 def test_groupnorm_many_blocks_reproducible(gpu):
     """More voxels than CVX_GN_BLOCKS * 2048 (blocks take several chunks) and a fixed-order reduction: the group sums match
-    float64 sums of the bf16 inputs to fp32 round-off and repeated calls are bit-identical (no atomics)."""
+    float64 sums of the fp16 inputs to fp32 round-off and repeated calls are bit-identical (no atomics)."""
     from cryovit_amd.engine import ops
 
     C, G, nvox = 16, 8, 1024 * 2048 + 12345
     g = torch.Generator(device=gpu).manual_seed(5)
-    x = (torch.randn(nvox, C, device=gpu, generator=g) * 2 + 0.3).to(torch.bfloat16)
+    x = (torch.randn(nvox, C, device=gpu, generator=g) * 2 + 0.3).to(torch.float16)
     w, b = torch.ones(C, device=gpu), torch.zeros(C, device=gpu)
     stats = torch.zeros(ops.gn_stats_size(G), device=gpu)
     outs = []
@@ -287,7 +335,7 @@ def test_groupnorm_many_blocks_reproducible(gpu):
     mean = want[:G] / (nvox * 2)
     var = want[G:] / (nvox * 2) - mean**2
     ref = ((x[:4096].float().cpu().reshape(-1, G, 2) - mean.float()[None, :, None]) / torch.sqrt(var.float() + 1e-3)[None, :, None]).reshape(-1, C)
-    assert torch.allclose(outs[0][0][:4096].float().cpu(), ref, atol=3e-2, rtol=1e-2)
+    assert torch.allclose(outs[0][0][:4096].float().cpu(), ref, atol=4e-3, rtol=2e-3)
 
 
 @pytest.mark.parametrize("Cin,Cout,dil,D,H,W", [(128, 24, 32, 8, 4, 4), (32, 16, 2, 6, 8, 8), (8, 8, 1, 5, 9, 11), (192, 192, 3, 7, 5, 6),
@@ -296,17 +344,17 @@ def test_conv3d(gpu, Cin, Cout, dil, D, H, W):
     from cryovit_amd.engine import ops
     from cryovit_amd.engine.head import _conv3_weight, _npad, _pad1
 
-    x = bf(rnd(D, H, W, Cin, seed=38))
+    x = hf(rnd(D, H, W, Cin, seed=38))
     w, b = rnd(Cout, Cin, 3, 3, 3, seed=39, scale=(27 * Cin) ** -0.5), rnd(Cout, seed=40)
     nv = D * H * W
-    out = torch.full((nv + 8, Cout), 7.0, dtype=torch.bfloat16, device=gpu)
+    out = torch.full((nv + 8, Cout), 7.0, dtype=torch.float16, device=gpu)
     zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
     ops.conv3d(x.to(gpu), _conv3_weight(w).to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=Cin, D=D, H=H, W=W, dil=dil,
                cout=Cout, act=1)
-    ref = F.gelu(F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), bf(w).float(), b, padding="same", dilation=(dil, 1, 1)))
+    ref = F.gelu(F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), hf(w).float(), b, padding="same", dilation=(dil, 1, 1)))
     ref = ref[0].permute(1, 2, 3, 0).reshape(nv, Cout)
     got = out[:nv].float().cpu()
-    assert torch.allclose(got, ref, atol=2e-2, rtol=1e-2), float((got - ref).abs().max())
+    assert torch.allclose(got, ref, atol=3e-3, rtol=2e-3), float((got - ref).abs().max())  # fp16 operands, fp32 accumulation
     assert torch.all(out[nv:].float() == 7.0)
 
 
@@ -318,26 +366,26 @@ def test_conv_transpose(gpu, c2, c3):
 
     D, H, W = 3, 5, 6
     nv = D * H * W
-    x = bf(rnd(nv, c2, seed=41))
+    x = hf(rnd(nv, c2, seed=41))
     wt, b = rnd(c2, c3, 1, 2, 2, seed=42, scale=c2**-0.5), rnd(c3, seed=43)
-    A = torch.zeros(ops.alloc_rows(nv) * c2 + 4096, dtype=torch.bfloat16)
+    A = torch.zeros(ops.alloc_rows(nv) * c2 + 4096, dtype=torch.float16)
     A[: nv * c2] = x.reshape(-1)
     A = A.to(gpu)
     a2 = torch.as_strided(A, (ops.alloc_rows(nv), c2), (c2, 1))
     wg = wt[:, :, 0].permute(2, 3, 1, 0).reshape(4 * c3, c2)
-    out = torch.zeros(D, 2 * H, 2 * W, c3, dtype=torch.bfloat16, device=gpu)
+    out = torch.zeros(D, 2 * H, 2 * W, c3, dtype=torch.float16, device=gpu)
     ops.gemm(EPI_CONVT, a2, _pad2(wg, _npad(4 * c3), ops.round_up(c2, 64)).to(gpu), out, _pad1(b.repeat(4), _npad(4 * c3)).to(gpu),
              m=nv, n=4 * c3, H=H, W=W, cout=c3, act=1, ldc=c3)
     xin = x.float().reshape(D, H, W, c2).permute(3, 0, 1, 2).unsqueeze(0)
-    ref = F.gelu(F.conv_transpose3d(xin, bf(wt).float(), b, stride=(1, 2, 2)))[0].permute(1, 2, 3, 0)
-    assert torch.allclose(out.float().cpu(), ref, atol=2e-2, rtol=1e-2), float((out.float().cpu() - ref).abs().max())
+    ref = F.gelu(F.conv_transpose3d(xin, hf(wt).float(), b, stride=(1, 2, 2)))[0].permute(1, 2, 3, 0)
+    assert torch.allclose(out.float().cpu(), ref, atol=3e-3, rtol=2e-3), float((out.float().cpu() - ref).abs().max())
 
 
 def test_conv3_out_fused_and_dice(gpu, gold):
     from cryovit_amd.engine import ops
 
     D, H, W = 6, 16, 70
-    x = bf(rnd(D, H, W, 8, seed=44))
+    x = hf(rnd(D, H, W, 8, seed=44))
     w, b = rnd(1, 8, 3, 3, 3, seed=45, scale=0.3), 0.1
     labels = torch.from_numpy(np.random.default_rng(46).integers(-1, 2, size=(D, H, W)).astype(np.int8))
     logits = torch.zeros(D, H, W, device=gpu)

@@ -113,7 +113,7 @@ def test_end_to_end_runner_configs_2_and_3(gpu, tmp_path):
     assert [r["tomo_name"] for r in rows_e2e] == ["t0.hdf", "t1.hdf", "t2.hdf"]
     for a, b in zip(rows_e2e, rows_feat):
         assert 0.0 < a["dice_metric"] < 1.0
-        assert abs(a["dice_metric"] - b["dice_metric"]) <= 2e-3  # fp16 feature file vs bf16 in-HBM hand-over
+        assert a["dice_metric"] == b["dice_metric"]  # the file and the in-HBM hand-over carry the same fp16 features
     got = {r["tomo_name"]: float(r["dice_metric"]) for r in csv.DictReader(open(tmp_path / "res_feat" / "results" / "Q109.csv"))}
     assert got == {r["tomo_name"]: r["dice_metric"] for r in rows_feat}
     pred = tmp_path / "res_feat" / "predictions" / "Q109" / "t1.hdf"
@@ -125,8 +125,8 @@ def test_end_to_end_runner_configs_2_and_3(gpu, tmp_path):
 def test_run_inference_against_oracle(gpu, tmp_path):
     """``cryovit infer`` (run/infer_model.py:18-85 + PredictionWriter, callbacks.py:81-109) on files that hold
     ``dino_features``: result files, key names, dtypes, and the uint8 segmentation against the fp32 oracle head.
-    bf16 activation storage moves logits by up to ~0.2 (tests/test_gpu_model.py), so disagreement is only allowed for
-    voxels whose oracle logit lies that close to the threshold."""
+    The fp16 head stays within 5e-2 of the fp32 logits (tests/test_gpu_model.py), so disagreement is only allowed for voxels
+    whose oracle logit lies that close to the threshold."""
     from typer.testing import CliRunner
 
     from cryovit_amd import io
@@ -166,7 +166,7 @@ def test_run_inference_against_oracle(gpu, tmp_path):
             logits = ref.forward_volume(torch.from_numpy(feats).float()[None])[0, 0].numpy()
         want = (1.0 / (1.0 + np.exp(-logits)) >= thr).astype(np.uint8)
         bad = seg != want
-        assert bad.mean() <= 0.05 and np.all(np.abs(logits[bad] - logit_thr) < 0.25), (bad.mean(), np.abs(logits[bad] - logit_thr).max())
+        assert bad.mean() <= 0.01 and np.all(np.abs(logits[bad] - logit_thr) < 0.05), (bad.mean(), np.abs(logits[bad] - logit_thr).max())
         assert 0.02 < seg.mean() < 0.98  # the synthetic head produces both classes
     # the same through the command line (cli/infer_cli.py): folder argument, --model, --result-folder, --threshold
     res = CliRunner().invoke(cli, ["infer", str(tmp_path / "in"), "--model", str(tmp_path / "demo.model"), "--result-folder",
@@ -181,7 +181,7 @@ def test_run_inference_against_oracle(gpu, tmp_path):
 def test_features_cli_then_infer_and_on_the_fly_encoder(gpu, tmp_path):
     """``cryovit features`` (run_dino, run/dino_features.py:211-299) on an .mrc and an .hdf tomogram, then ``infer`` on the
     produced files; and the build's shortcut -- ``run_inference(..., encoder=)`` on the raw files -- must give the same
-    segmentation up to the fp16-file vs bf16-in-HBM hand-over of the features."""
+    segmentation (both hand fp16 features to the head; the two copies come from the same LayerNorm in one kernel)."""
     import struct
 
     from typer.testing import CliRunner
@@ -227,7 +227,7 @@ def test_features_cli_then_infer_and_on_the_fly_encoder(gpu, tmp_path):
     assert [p.name for p in on_the_fly] == ["a.hdf", "b.hdf"]
     for p, q in zip(from_files, on_the_fly):
         s0, s1 = io.read_dataset(p, "mito_preds"), io.read_dataset(q, "mito_preds")
-        assert s0.shape == s1.shape and (s0 != s1).mean() <= 0.01, (s0 != s1).mean()
+        assert s0.shape == s1.shape and np.array_equal(s0, s1)  # identical fp16 features either way -> identical segmentation
         assert np.array_equal(io.read_dataset(p, "data"), io.read_dataset(q, "data"))
     # without an encoder a file lacking dino_features fails like the reference: KeyError from the HDF5 lookup
     with pytest.raises(KeyError):
