@@ -33,7 +33,9 @@ __device__ __forceinline__ void ln_row_stats(const float* row, int C4, int lane,
     rstd = rsqrtf(wave_sum(q) / (float)C + eps);
 }
 
-__global__ __launch_bounds__(256) void k_layernorm_bf16(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+// Narrow rows (C < 1024: ViT-S/B, the Hiera stages): 4 channels per lane and step keeps more of the 64 lanes busy; plain
+// loads, because these activations are small enough to still sit in the L2 / MALL when the LayerNorm reads them.
+__global__ __launch_bounds__(256) void k_layernorm_bf16_v4(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                         const float* __restrict__ b, uint16_t* __restrict__ out, long ldo,
                                                         long rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -52,6 +54,76 @@ __global__ __launch_bounds__(256) void k_layernorm_bf16(const float* __restrict_
             o.x = pack2bf((v[j].x - mean) * rstd * ww.x + bb.x, (v[j].y - mean) * rstd * ww.y + bb.y);
             o.y = pack2bf((v[j].z - mean) * rstd * ww.z + bb.z, (v[j].w - mean) * rstd * ww.w + bb.w);
             *(uint2*)(out + row * ldo + 4 * i) = o;
+        }
+    }
+}
+
+
+// LN_V8: 8 consecutive channels per lane and step (two adjacent 16-B loads, ONE 16-B store of 8 bf16) -- full-width stores
+// instead of the 8-B ones of the float4 mapping; LN_ROWS rows per wave keep twice the loads in flight.
+constexpr int LN_MAXJ8 = 4;   // 8-channel chunks per lane: C <= 64*8*4 = 2048
+constexpr int LN_ROWS = 2;
+
+__global__ __launch_bounds__(256) void k_layernorm_bf16(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, uint16_t* __restrict__ out, long ldo,
+                                                        long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_ROWS;
+    if (row0 >= rows) return;
+    const int C8 = C >> 3;
+    f32x4 v[LN_ROWS][LN_MAXJ8][2];
+    float s[LN_ROWS];
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        s[r] = 0.f;
+        const long row = row0 + r < rows ? row0 + r : rows - 1;  // the clamped duplicate is computed and not stored
+        const float* xr = x + row * ldx;
+#pragma unroll
+        for (int j = 0; j < LN_MAXJ8; ++j) {
+            const int i = lane + 64 * j;
+            if (i < C8) {
+                v[r][j][0] = __builtin_nontemporal_load((const f32x4*)(xr + 8 * i));
+                v[r][j][1] = __builtin_nontemporal_load((const f32x4*)(xr + 8 * i + 4));
+                s[r] += ((v[r][j][0].x + v[r][j][0].y) + (v[r][j][0].z + v[r][j][0].w)) +
+                        ((v[r][j][1].x + v[r][j][1].y) + (v[r][j][1].z + v[r][j][1].w));
+            }
+        }
+    }
+    float mean[LN_ROWS], rstd[LN_ROWS];
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        mean[r] = wave_sum(s[r]) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXJ8; ++j) {
+            if (lane + 64 * j < C8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float a0 = v[r][j][h].x - mean[r], a1 = v[r][j][h].y - mean[r], a2 = v[r][j][h].z - mean[r],
+                                a3 = v[r][j][h].w - mean[r];
+                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+        }
+        rstd[r] = rsqrtf(wave_sum(q) / (float)C + eps);
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < C8) {
+            const float4 w0 = *(const float4*)(w + 8 * i), w1 = *(const float4*)(w + 8 * i + 4);
+            const float4 b0 = *(const float4*)(b + 8 * i), b1 = *(const float4*)(b + 8 * i + 4);
+#pragma unroll
+            for (int r = 0; r < LN_ROWS; ++r) {
+                if (row0 + r >= rows) continue;
+                const float m = mean[r], rs = rstd[r];
+                uint4 o;
+                o.x = pack2bf((v[r][j][0].x - m) * rs * w0.x + b0.x, (v[r][j][0].y - m) * rs * w0.y + b0.y);
+                o.y = pack2bf((v[r][j][0].z - m) * rs * w0.z + b0.z, (v[r][j][0].w - m) * rs * w0.w + b0.w);
+                o.z = pack2bf((v[r][j][1].x - m) * rs * w1.x + b1.x, (v[r][j][1].y - m) * rs * w1.y + b1.y);
+                o.w = pack2bf((v[r][j][1].z - m) * rs * w1.z + b1.z, (v[r][j][1].w - m) * rs * w1.w + b1.w);
+                *(uint4*)(out + (row0 + r) * ldo + 8 * i) = o;
+            }
         }
     }
 }
@@ -259,8 +331,13 @@ using namespace cvx;
 extern "C" int cvx_layernorm_bf16(const float* x, long ldx, const float* w, const float* b, void* out, long ldo,
                                   long rows, int C, float eps, hipStream_t st) {
     if (rows <= 0) return 0;
-    if (C % 4 || C > 64 * 4 * LN_MAXJ || ldx % 4 || ldo % 4) return cvx_fail("layernorm: C%4==0, C<=2048, ld%4==0 required");
-    hipLaunchKernelGGL(k_layernorm_bf16, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, w, b, (uint16_t*)out,
+    if (C % 4 || C > 2048 || ldx % 4 || ldo % 4) return cvx_fail("layernorm: C%4==0, C<=2048, ld%4==0 required");
+    if (C < 1024 || C % 8 || ldo % 8) {
+        hipLaunchKernelGGL(k_layernorm_bf16_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, w, b, (uint16_t*)out, ldo, rows, C,
+                           eps);
+        return cvx_check_launch();
+    }
+    hipLaunchKernelGGL(k_layernorm_bf16, dim3((unsigned)((rows + 4 * LN_ROWS - 1) / (4 * LN_ROWS))), dim3(256), 0, st, x, ldx, w, b, (uint16_t*)out,
                        ldo, rows, C, eps);
     return cvx_check_launch();
 }
