@@ -13,6 +13,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define CVX_GLOBAL_AS __attribute__((address_space(1)))
 #define CVX_LDS_AS __attribute__((address_space(3)))
 
+#ifndef CVX_STREAM_IO
+#define CVX_STREAM_IO 1
+#endif
+constexpr bool g_stream_io = CVX_STREAM_IO;
+
 __device__ __forceinline__ uint16_t f2bf(float f) {
     // plain cast: hipcc emits v_cvt_pk_bf16_f32 on gfx950 (RNE, NaN stays NaN)
     __bf16 b = (__bf16)f;
@@ -65,6 +70,22 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x));
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const CVX_GLOBAL_AS void*)gsrc, (CVX_LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+// Streaming (non-temporal) 16-B accesses for tensors that are written once and read once by a later kernel: the
+// residual stream and the GEMM outputs are far larger than the L2, keeping them out of it leaves the L2 to the operand panels.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+__device__ __forceinline__ float4 ld_stream(const float* p) {
+    const f32x4 v = g_stream_io ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p;
+    return float4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void st_stream(float* p, const float4& v) {
+    const f32x4 t{v.x, v.y, v.z, v.w};
+    if (g_stream_io) __builtin_nontemporal_store(t, (f32x4*)p); else *(f32x4*)p = t;
+}
+__device__ __forceinline__ void st_stream(uint16_t* p, const uint4& v) {
+    const u32x4 t{v.x, v.y, v.z, v.w};
+    if (g_stream_io) __builtin_nontemporal_store(t, (u32x4*)p); else *(u32x4*)p = t;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -429,7 +429,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long m = mbase + 4 * i;
-                xv[i] = (m < epi.m_valid && nglob < epi.n_valid) ? *(const float4*)(epi.x + m * epi.ldx + nglob) : float4{0.f, 0.f, 0.f, 0.f};
+                xv[i] = (m < epi.m_valid && nglob < epi.n_valid) ? ld_stream(epi.x + m * epi.ldx + nglob) : float4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -438,7 +438,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
                 if (m < epi.m_valid && nglob < epi.n_valid) {
                     float4 o;
                     o.x = xv[i].x + d.x; o.y = xv[i].y + d.y; o.z = xv[i].z + d.z; o.w = xv[i].w + d.w;
-                    *(float4*)(epi.x + m * epi.ldx + nglob) = o;
+                    st_stream(epi.x + m * epi.ldx + nglob, o);
                 }
             }
         }
@@ -475,7 +475,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
                 const int row = RPI * i + srow;
                 const long m = l0 + wl * 128 + 32 * q + row;
                 const uint4 d = *(const uint4*)(stg + row * PITCHB + spiece * 16);
-                if (m < epi.m_valid && ocol < ovalid) *(uint4*)(epi.out + m * epi.ldc + ocol) = d;
+                if (m < epi.m_valid && ocol < ovalid) st_stream(epi.out + m * epi.ldc + ocol, d);
             }
         }
     } else {
