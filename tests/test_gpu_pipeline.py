@@ -232,3 +232,39 @@ def test_features_cli_then_infer_and_on_the_fly_encoder(gpu, tmp_path):
     # without an encoder a file lacking dino_features fails like the reference: KeyError from the HDF5 lookup
     with pytest.raises(KeyError):
         run_inference([tmp_path / "raw" / "a.hdf"], tmp_path / "e2e.model", tmp_path / "seg_fail")
+
+
+def test_graph_replay_equals_eager_config1_size(gpu):
+    """hipGraph replay of the whole per-tomogram sequence (resize + ViT + head + Dice) is bit-identical to eager launches,
+    for two different tomograms through ONE captured graph.  BASELINE configs[0] geometry (64x256x256) on ViT-g so that the
+    1536-channel head can follow; depth cut to 16 slices to keep the test short."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.graph import GraphedTomogram
+    from cryovit_amd.engine.head import HeadEngine
+    from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine, random_state_dict
+
+    cfg = VIT_CONFIGS["dinov2_vitg14_reg"]
+    vit = VitEngine(cfg, random_state_dict(cfg, seed=2, device=gpu), gpu)
+    head = HeadEngine(bench.synthetic_head_state_dict(5, gpu), gpu)
+    D, H, W = 16, 256, 256
+    g = GraphedTomogram(vit, head, D, H, W, slice_batch=8, mask_threshold=0.5)
+    rng = np.random.default_rng(3)
+    for seed in (1, 2):
+        vol = torch.from_numpy(rng.integers(0, 256, (D, H, W), dtype=np.uint8)).to(gpu)
+        labels = torch.from_numpy(rng.integers(-1, 2, (D, H, W)).astype(np.int8)).to(gpu)
+        out = g.run(vol, labels)
+        probs, dice, mask, f16 = out["probs"].clone(), out["dice_sums"].clone(), out["mask"].clone(), out["feats_f16"].clone()
+        f16_e = torch.zeros_like(f16)
+        cl = torch.zeros(ops.alloc_rows(D * 16 * 16), cfg.dim, dtype=torch.float16, device=gpu)
+        for d0 in range(0, D, 8):
+            vit.features(vol[d0 : d0 + 8], feats_f16=f16_e, d_total=D, d0=d0, feats_cl=cl[d0 * 256 :])
+        ref = head.forward(cl, D, 16, 16, labels=labels, mask_threshold=0.5)
+        assert torch.equal(f16, f16_e) and torch.equal(probs, ref["probs"]) and torch.equal(mask, ref["mask"])
+        assert torch.equal(dice, ref["dice_sums"]) and float(dice[1]) > 0
+    with pytest.raises(ValueError):
+        g.run(torch.zeros(D, H, W + 16, dtype=torch.uint8, device=gpu))
