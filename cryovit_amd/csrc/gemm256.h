@@ -475,7 +475,12 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
                 const int row = RPI * i + srow;
                 const long m = l0 + wl * 128 + 32 * q + row;
                 const uint4 d = *(const uint4*)(stg + row * PITCHB + spiece * 16);
-                if (m < epi.m_valid && ocol < ovalid) st_stream(epi.out + m * epi.ldc + ocol, d);
+                if (m < epi.m_valid && ocol < ovalid) {
+                    // 128-B row segments stream past the L2; the 64-B segments of the gated output are left to the L2's write
+                    // combining (as streaming stores they reached memory as half lines: WRITE_SIZE 1.31 GB for 1.08 GB written)
+                    if constexpr (O16 == 16) st_stream(epi.out + m * epi.ldc + ocol, d);
+                    else *(uint4*)(epi.out + m * epi.ldc + ocol) = d;
+                }
             }
         }
     } else {
