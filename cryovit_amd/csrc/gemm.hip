@@ -446,12 +446,15 @@ extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
     return 0;
 }
 
+static int g_conv_halo = 1;  // cvx_set_option("conv_halo", 0) forces the implicit-GEMM kernel (A/B runs, tests)
+
 extern "C" int cvx_set_option(const char* name, int value) {
     if (!name) return cvx_fail("set_option: null name");
     if (!strcmp(name, "use_gemm256")) g_use_gemm256 = value;
     else if (!strcmp(name, "gemm256_variant")) g_gemm256_variant = value;
     else if (!strcmp(name, "gemm_stagger")) g_gemm_stagger = value;
     else if (!strcmp(name, "gemm_tail_split")) g_tail_split = value;
+    else if (!strcmp(name, "conv_halo")) g_conv_halo = value;
     else if (!strcmp(name, "attn_variant")) g_attn_variant = value;
     else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value;
     else if (!strcmp(name, "tile_group_l")) {
@@ -580,10 +583,16 @@ static int conv3_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
     return cvx_fail("conv3d: C_out must be padded to a multiple of 16");
 }
 
+namespace cvx {  // conv_halo.hip: LDS-halo kernel for the full-resolution few-channel layers
+bool conv3_halo_eligible(const cvx_conv3d_desc& d);
+int conv3_halo_dispatch(const cvx_conv3d_desc& d, hipStream_t st);
+}
+
 extern "C" int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t st) {
     if (!d) return cvx_fail("conv3d: null descriptor");
     if (d->C % 8) return cvx_fail("conv3d: C_in must be a multiple of 8");
     if (d->k_pad % BK || d->k_pad < 27 * d->C) return cvx_fail("conv3d: K must be 27*C_in padded to a multiple of 64");
     if (d->cout % 4) return cvx_fail("conv3d: C_out must be a multiple of 4");
+    if (g_conv_halo && conv3_halo_eligible(*d)) return conv3_halo_dispatch(*d, st);
     return d->act ? conv3_dispatch<1>(*d, st) : conv3_dispatch<0>(*d, st);
 }

@@ -358,6 +358,37 @@ def test_conv3d(gpu, Cin, Cout, dil, D, H, W):
     assert torch.all(out[nv:].float() == 7.0)
 
 
+@pytest.mark.parametrize("Cin,Cout,dil,D,H,W", [(32, 16, 2, 7, 9, 70), (16, 16, 1, 5, 12, 131), (8, 8, 1, 4, 7, 66), (16, 8, 3, 6, 4, 64),
+                                               (32, 12, 1, 3, 5, 33)])
+def test_conv3d_halo_kernel(gpu, Cin, Cout, dil, D, H, W):
+    """The LDS-halo kernel of the full-resolution few-channel layers (C_in 8/16/32, C_out <= 16): ragged tiles in x and y,
+    dilation in z reaching outside the volume, C_out 8 / 12 / 16 -- against torch, and against the implicit-GEMM kernel the
+    same call uses when the option is off (same fp16 operands, fp32 accumulation in a different order)."""
+    from cryovit_amd import _lib
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _conv3_weight, _npad, _pad1
+
+    x = hf(rnd(D, H, W, Cin, seed=58))
+    w, b = rnd(Cout, Cin, 3, 3, 3, seed=59, scale=(27 * Cin) ** -0.5), rnd(Cout, seed=60)
+    nv = D * H * W
+    zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
+    outs = []
+    for halo in (1, 0):
+        _lib.set_option("conv_halo", halo)
+        out = torch.full((nv + 8, Cout), 7.0, dtype=torch.float16, device=gpu)
+        ops.conv3d(x.to(gpu), _conv3_weight(w).to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=Cin, D=D, H=H, W=W, dil=dil,
+                   cout=Cout, act=1)
+        outs.append(out)
+    _lib.set_option("conv_halo", 1)
+    ref = F.gelu(F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), hf(w).float(), b, padding="same", dilation=(dil, 1, 1)))
+    ref = ref[0].permute(1, 2, 3, 0).reshape(nv, Cout)
+    for out in outs:
+        got = out[:nv].float().cpu()
+        assert torch.allclose(got, ref, atol=3e-3, rtol=2e-3), float((got - ref).abs().max())
+        assert torch.all(out[nv:].float() == 7.0)
+    assert float((outs[0][:nv].float() - outs[1][:nv].float()).abs().max()) <= 4e-3
+
+
 @pytest.mark.parametrize("c2,c3", [(24, 16), (192, 128), (16, 8)])
 def test_conv_transpose(gpu, c2, c3):
     from cryovit_amd._lib import EPI_CONVT
