@@ -63,6 +63,12 @@ class CryoVIT(nn.Module):
         self._engine = None
         return r
 
+    def _check_channels(self, C: int) -> None:
+        c_in = self.layers[0].weight.shape[1]
+        if C != c_in:
+            raise ValueError(f"CryoVIT expects {c_in}-channel input features ('{self.input_key}'), got {C} channels: run the feature "
+                             "stage first (cryovit features / training.dino_features) or pass an encoder to run_inference")
+
     def engine(self) -> HeadEngine:
         if self._engine is None:
             self._engine = HeadEngine(self.state_dict(), self._device)
@@ -74,6 +80,7 @@ class CryoVIT(nn.Module):
         outs = []
         for xb in x:
             C, D, h, w = xb.shape
+            self._check_channels(C)
             cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.float16, device=self._device)
             src = xb.to(self._device)
             if src.dtype == torch.float16 and src.is_contiguous():
@@ -96,6 +103,7 @@ class CryoVIT(nn.Module):
         outs = []
         for xb in batch.tomo_batch:  # [D,C,h,w]
             D, C, h, w = xb.shape
+            self._check_channels(C)
             cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.float16, device=self._device)
             cl[: D * h * w] = xb.to(self._device).permute(0, 2, 3, 1).reshape(-1, C).to(torch.float16)
             outs.append(self.engine().forward(cl, D, h, w, want_probs=False, mask_threshold=threshold)["mask"])
