@@ -96,6 +96,20 @@ def _ohdr_v1(msgs: list[bytes]) -> bytes:
     return struct.pack("<BxHII4x", 1, len(msgs), 1, len(body)) + body
 
 
+_POOL = None
+
+
+def _pool():
+    """Shared worker threads for chunk (de)compression."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        _POOL = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2))), thread_name_prefix="h5z")
+    return _POOL
+
+
 class H5Writer:
     """``with H5Writer(path) as f: f.create_dataset("labels/mito", arr, compression="gzip")``"""
 
@@ -162,15 +176,17 @@ class H5Writer:
             c0 = max(1, -(-arr.shape[0] // (2 * CHUNK_K)))
             chunk = (c0,) + tuple(arr.shape[1:])
             nchunk = -(-arr.shape[0] // c0)
-            entries = []
-            for i in range(nchunk):
+            def deflate(i):
                 blk = arr[i * c0 : (i + 1) * c0]
                 if blk.shape[0] < c0:  # edge chunk: pad to the full chunk extent
                     padded = np.zeros(chunk, dtype=arr.dtype)
                     padded[: blk.shape[0]] = blk
                     blk = padded
-                comp = zlib.compress(blk.tobytes(), ds.level)
-                entries.append((len(comp), i * c0, self._alloc_write(comp)))
+                return zlib.compress(blk.tobytes(), ds.level)
+
+            # zlib releases the GIL: chunks are deflated in parallel, written in order (the file layout does not change)
+            comps = list(_pool().map(deflate, range(nchunk))) if nchunk > 1 and arr.nbytes >= (1 << 20) else [deflate(i) for i in range(nchunk)]
+            entries = [(len(comp), i * c0, self._alloc_write(comp)) for i, comp in enumerate(comps)]
             key_fmt_offsets = rank + 1
             node = bytearray(b"TREE" + struct.pack("<BBHQQ", 1, 0, nchunk, UNDEF, UNDEF))
             for size, off0, addr in entries:
@@ -271,8 +287,8 @@ class H5Dataset:
             btree, chunk = self._layout[1], self._layout[2]
             out = np.zeros(self.shape, dtype=self.dtype)
             if btree != UNDEF:
-                for csize, mask, offs, caddr in self._f._iter_chunks(btree, len(self.shape)):
-                    raw = self._f._read(caddr, csize)
+                def inflate(item):
+                    mask, offs, raw = item
                     for idx, (fid, _cd) in reversed(list(enumerate(self._filters))):
                         if mask & (1 << idx):  # filter skipped for this chunk
                             continue
@@ -285,7 +301,15 @@ class H5Dataset:
                             raise H5Error(f"unsupported filter id {fid}")
                     blk = np.frombuffer(raw, dtype=self.dtype).reshape(chunk)
                     sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, chunk, self.shape))
-                    out[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]
+                    out[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]  # chunks are disjoint: safe from several threads
+
+                # file reads stay serial (one handle); inflating + scattering the chunks runs in parallel (zlib drops the GIL)
+                items = [(mask, offs, self._f._read(caddr, csize)) for csize, mask, offs, caddr in self._f._iter_chunks(btree, len(self.shape))]
+                if len(items) > 1 and out.nbytes >= (1 << 20):
+                    list(_pool().map(inflate, items))
+                else:
+                    for it in items:
+                        inflate(it)
             return out
         raise H5Error(f"unsupported layout {kind}")
 
