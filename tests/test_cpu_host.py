@@ -198,3 +198,36 @@ def test_prediction_file_formats(tmp_path):
     seg = io.read_dataset(q, "mito_preds")
     assert seg.dtype == np.uint8 and np.array_equal(seg, (preds >= 0.5).astype(np.uint8))
     assert io.read_dataset(q, "data").dtype == np.float32
+
+
+def test_sam_feature_file_layout_and_config(tmp_path):
+    """``_save_data`` with SAM features (run/dino_features.py:133-146): ``sam_features/<key>/<level>`` uncompressed, the source's
+    ``dino_features`` kept; ``sam_features`` config (configs/sam_features.yaml: use_sam, model = sam2, SAM2 model dir)."""
+    import numpy as np
+
+    from cryovit_amd import io
+    from cryovit_amd.config import compose
+    from cryovit_amd.engine.hiera import HIERA_CONFIGS
+    from cryovit_amd.run.dino_features import _save_data
+    from oracle import sam2_hiera as oh
+
+    cfg = compose("sam_features", ["paths.model_dir=/m", "paths.data_dir=/d", "paths.exp_dir=/e", "sample=Q109"])
+    assert cfg.use_sam is True and cfg.model.name == "SAM2" and cfg.model_dir == "/m/SAM2" and cfg.batch_size == 128
+    assert HIERA_CONFIGS["sam2.1_hiera_l"].block_plan() == oh.HIERA_L.block_plan()  # engine plan == oracle plan (pinned vs HF)
+    rng = np.random.default_rng(0)
+    data = {"data": rng.integers(0, 255, (3, 8, 8), dtype=np.uint8), "mito": rng.integers(-1, 2, (3, 8, 8)).astype(np.int8),
+            "dino_features": rng.standard_normal((4, 3, 1, 1)).astype(np.float16)}
+    feats = {"vision_pos_enc": [np.broadcast_to(rng.standard_normal((1, 6, 2, 2)).astype(np.float16), (3, 6, 2, 2)),
+                                rng.standard_normal((3, 6, 1, 1)).astype(np.float16)],
+             "backbone_fpn": [rng.standard_normal((3, 6, 2, 2)).astype(np.float16), rng.standard_normal((3, 6, 1, 1)).astype(np.float16)]}
+    _save_data(data, feats, "t.hdf", tmp_path)
+    out = tmp_path / "t.hdf"
+    assert sorted(io.list_keys(out)) == ["data", "dino_features", "labels", "sam_features"]
+    assert sorted(io.list_keys(out, "sam_features")) == ["backbone_fpn", "vision_pos_enc"]
+    assert io.list_keys(out, "sam_features/backbone_fpn") == ["0", "1"]
+    for key, arrs in feats.items():
+        for i, a in enumerate(arrs):
+            got = io.read_dataset(out, f"sam_features/{key}/{i}")
+            assert got.dtype == np.float16 and np.array_equal(got, a)
+    assert np.array_equal(io.read_dataset(out, "dino_features"), data["dino_features"])
+    assert np.array_equal(io.read_dataset(out, "labels/mito"), data["mito"])
