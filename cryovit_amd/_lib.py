@@ -10,7 +10,7 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libcryovit_hip.so"
 
-EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT = range(7)
+EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT, EPI_F32 = range(8)
 DTYPE_BF16, DTYPE_F16 = 0, 1  # CVX_DTYPE_*
 DICE_BLOCKS = 4096  # CVX_DICE_BLOCKS
 GN_BLOCKS = 1024  # CVX_GN_BLOCKS

@@ -113,7 +113,11 @@ struct EpiSwiGLU {
 };
 
 // residual stream update in fp32:  x[m][n] += gamma[n] * (acc + bias[n])
-struct EpiResid {
+// x[m][n] (+)= gamma[n] * (acc + bias[n]) on the fp32 stream.  ACC = true: read-modify-write (LayerScale + residual);
+// ACC = false: plain fp32 output (x is only written -- Hiera's projected shortcut, the FPN lateral convs)
+template <bool ACC>
+struct EpiResidT {
+    static constexpr bool ACCUM = ACC;
     float* x; long ldx; const float* bias; const float* gamma; long m_valid, n_valid;
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
@@ -124,14 +128,15 @@ struct EpiResid {
     // the residual values are PRE-LOADED for a batch of output columns before any of them is stored: issued one after
     // the other, each load -> add -> store round trip exposed a full HBM latency (32 per lane per tile: the epilogue
     // took as long as the whole K loop of the proj GEMM -- tools/stamp_gemm_coarse.py)
-    EpiResid shifted(long m_off) const { return EpiResid{x + m_off * ldx, ldx, bias, gamma, m_valid - m_off, n_valid}; }
+    EpiResidT shifted(long m_off) const { return EpiResidT{x + m_off * ldx, ldx, bias, gamma, m_valid - m_off, n_valid}; }
     static constexpr bool HAS_PRELOAD = true;
     template <int NV> struct Pre { float4 x[NV / 4]; };
     template <int NV>
     __device__ __forceinline__ void preload(Pre<NV>& p, long n0, long m) const {
         const long mm = m < m_valid ? m : 0;
 #pragma unroll
-        for (int h = 0; h < NV / 4; ++h) p.x[h] = *(const float4*)(x + mm * ldx + (n0 + h * 4 < n_valid ? n0 + h * 4 : 0));
+        for (int h = 0; h < NV / 4; ++h)
+            p.x[h] = ACC ? *(const float4*)(x + mm * ldx + (n0 + h * 4 < n_valid ? n0 + h * 4 : 0)) : float4{0.f, 0.f, 0.f, 0.f};
     }
     template <int NV>
     __device__ __forceinline__ void store(const Ctx<NV>& c, const Pre<NV>& p, long n0, long m, const float* acc) const {
@@ -155,6 +160,8 @@ struct EpiResid {
         store<NV>(c, p, n0, m, acc);
     }
 };
+using EpiResid = EpiResidT<true>;
+using EpiF32 = EpiResidT<false>;
 
 // patch embedding: GEMM row m = slice*npatch + p  ->  token row slice*ntp + tok0 + p of the fp32 stream,
 // value = acc + bias[n] + pos[(1+p)][n]
@@ -310,6 +317,7 @@ __global__ __launch_bounds__(G256_THREADS) void k_gemm256_mreg(const uint16_t* A
 static int g_use_gemm256 = 1, g_gemm256_variant = 5, g_gemm_stagger = 0;  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
 template <class Epi> static constexpr int epilogue_cycles() { return 12000; }       // bf16 store epilogues (stamped)
 template <> constexpr int epilogue_cycles<EpiResid>() { return 40000; }              // fp32 read-modify-write
+template <> constexpr int epilogue_cycles<EpiF32>() { return 20000; }
 
 template <class Epi, bool MREG, int VARIANT>
 __global__ __launch_bounds__(G4W_THREADS) void k_gemm4w(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nks,
@@ -524,6 +532,10 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         }
         case CVX_EPI_RESID: {
             EpiResid e{(float*)d->out, d->ldc, d->bias, d->gamma, d->m, d->n};
+            return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
+        case CVX_EPI_F32: {
+            EpiF32 e{(float*)d->out, d->ldc, d->bias, d->gamma, d->m, d->n};
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_PATCH: {

@@ -429,7 +429,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long m = mbase + 4 * i;
-                xv[i] = (m < epi.m_valid && nglob < epi.n_valid) ? ld_stream(epi.x + m * epi.ldx + nglob) : float4{0.f, 0.f, 0.f, 0.f};
+                xv[i] = (Epi::ACCUM && m < epi.m_valid && nglob < epi.n_valid) ? ld_stream(epi.x + m * epi.ldx + nglob) : float4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {

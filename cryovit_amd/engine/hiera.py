@@ -27,7 +27,7 @@ from dataclasses import dataclass
 import torch
 import torch.nn.functional as F
 
-from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU, EPI_PATCH, EPI_RESID
+from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_PATCH, EPI_RESID
 from cryovit_amd.engine import ops
 from cryovit_amd.engine.ops import alloc_rows, round_up
 
@@ -241,8 +241,7 @@ class HieraEngine:
                 qkv = self._buf(f"qkv_t{stage}", rows, 3 * dout, bf)
                 ops.gemm(EPI_BF16, xn, blk["qkv"][0], qkv, blk["qkv"][1], m=rows, n=3 * dout)
                 sc = self._buf(f"short{stage}", rows, dout, f32)
-                sc.zero_()
-                ops.gemm(EPI_RESID, xn, blk["short"][0], sc, blk["short"][1], gamma=self.ones, m=rows, n=dout)
+                ops.gemm(EPI_F32, xn, blk["short"][0], sc, blk["short"][1], gamma=self.ones, m=rows, n=dout)
                 if q_stride:
                     Gn = G // 2
                     nrows = b * Gn * Gn
@@ -284,8 +283,7 @@ class HieraEngine:
             xb = self._buf(f"neck_in{s}", r, round_up(c, 64), bf)
             ops.cast_bf16(xs, xb, rows=r, C=c)
             lat = self._buf(f"lat{s}", r, cfg.d_model, f32)
-            lat.zero_()
-            ops.gemm(EPI_RESID, xb, self.neck[s][0], lat, self.neck[s][1], gamma=self.ones, m=r, n=cfg.d_model)
+            ops.gemm(EPI_F32, xb, self.neck[s][0], lat, self.neck[s][1], gamma=self.ones, m=r, n=cfg.d_model)
             lats.append(lat)
         for s in range(n + 1 - cfg.scalp):
             _, g, _, _ = stage_out[s]

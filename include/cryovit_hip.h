@@ -60,7 +60,8 @@ enum cvx_epilogue {
     CVX_EPI_RESID = 3,     /* out fp32 [M][ldc]      += gamma * (acc + bias)     (LayerScale+residual)*/
     CVX_EPI_PATCH = 4,     /* out fp32 token stream: row slice*ntp+tok0+p = acc + bias + pos[1+p]     */
     CVX_EPI_VT = 5,        /* out bf16 V^T [slice][head][64][kp] = acc + bias   (for cvx_attention)   */
-    CVX_EPI_CONVT = 6      /* out bf16 [D][2H][2W][cout] pixel-shuffle of N = 4*cout, optional GELU   */
+    CVX_EPI_CONVT = 6,     /* out bf16 [D][2H][2W][cout] pixel-shuffle of N = 4*cout, optional GELU   */
+    CVX_EPI_F32 = 7        /* out fp32 [M][ldc]       = gamma * (acc + bias)   (written, not accumulated)  */
 };
 
 enum { CVX_DTYPE_BF16 = 0, CVX_DTYPE_F16 = 1 };

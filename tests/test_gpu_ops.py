@@ -99,6 +99,24 @@ def test_gemm_fp16_saturates_instead_of_inf(gpu):
         ops.gemm(EPI_RESID, A, Wd, torch.zeros(ops.alloc_rows(M), N, device=gpu), torch.zeros(N, device=gpu), gamma=torch.ones(N, device=gpu), m=M, n=N)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (2048, 1536, 576), (130, 144, 320)])
+def test_gemm_f32_output(gpu, M, N, K):
+    """CVX_EPI_F32: out fp32 = gamma * (acc + bias), WRITTEN (stale contents of the output must not leak in)."""
+    from cryovit_amd._lib import EPI_F32
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.hiera import _npad
+
+    a, w, b, gam = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=K**-0.5), rnd(N, seed=73), rnd(N, seed=74) + 1
+    n_pad, k_pad = _npad(N, K), ops.round_up(K, 64)
+    out = torch.full((ops.alloc_rows(M), N), float("nan"), device=gpu)  # NaN: any read-modify-write would show
+    ops.gemm(EPI_F32, padded_bf16(a, ops.alloc_rows(M), k_pad, gpu), padded_bf16(w, n_pad, k_pad, gpu), out, padded_f32(b, n_pad, gpu),
+             gamma=padded_f32(gam, n_pad + 256, gpu), m=M, n=N)
+    ref = gam * (bf(a).float() @ bf(w).float().T + b)
+    got = out[:M].cpu()
+    assert torch.allclose(got, ref, atol=2e-3, rtol=1e-3), float((got - ref).abs().max())
+    assert torch.isnan(out[M:]).all(), "rows beyond M were written"
+
+
 def test_gemm_swiglu(gpu):
     from cryovit_amd._lib import EPI_SWIGLU
     from cryovit_amd.engine import ops
