@@ -8,7 +8,11 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libcryovit_hip.so"
+import os
+
+# CVX_ABLATION_LIB=1 (tools/ only): the -DCVX_ABLATION build with the timing-only kernel variants (cryovit_amd/build.py)
+LIB_PATH = Path(__file__).resolve().parent / ("libcryovit_hip_ablation.so" if os.environ.get("CVX_ABLATION_LIB") == "1"
+                                                else "libcryovit_hip.so")
 
 EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT, EPI_F32 = range(8)
 DTYPE_BF16, DTYPE_F16 = 0, 1  # CVX_DTYPE_*

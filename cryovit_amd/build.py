@@ -1,6 +1,10 @@
 """Builds ``libcryovit_hip.so`` (gfx950) in-tree with hipcc.  No torch involved: the library is a plain C ABI.
 
-    python -m cryovit_amd.build [--force]
+    python -m cryovit_amd.build [--force] [--ablation]
+
+``--ablation`` builds ``libcryovit_hip_ablation.so`` with ``-DCVX_ABLATION``: the product library plus the timing-only GEMM /
+attention variants (in-kernel stamps, schedules with parts removed whose OUTPUT IS GARBAGE).  Only ``tools/`` loads it
+(``CVX_ABLATION_LIB=1``); the product library does not contain those kernels and rejects their option values.
 
 hipcc cross-compiles without a GPU, so this also runs in the (GPU-less) build container; the resulting
 ``.so`` is git-ignored but travels to the GPU box with the repo snapshot.
@@ -48,17 +52,22 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def build_library(force: bool = False, verbose: bool = False) -> Path:
-    stamp = BUILD_DIR / "fingerprint"
-    fp = _fingerprint()
-    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == fp:
-        return LIB
-    BUILD_DIR.mkdir(exist_ok=True)
+ABLATION_LIB = PKG / "libcryovit_hip_ablation.so"
+
+
+def build_library(force: bool = False, verbose: bool = False, ablation: bool = False) -> Path:
+    lib, build_dir = (ABLATION_LIB, PKG / "build_ablation") if ablation else (LIB, BUILD_DIR)
+    extra = ["-DCVX_ABLATION"] if ablation else []
+    stamp = build_dir / "fingerprint"
+    fp = _fingerprint() + ("+ablation" if ablation else "")
+    if not force and lib.exists() and stamp.exists() and stamp.read_text() == fp:
+        return lib
+    build_dir.mkdir(exist_ok=True)
     hipcc = hipcc_path()
 
     def compile_one(src: Path) -> Path:
-        obj = BUILD_DIR / (src.stem + ".o")
-        cmd = [hipcc, *FLAGS, *FILE_FLAGS.get(src.name, []), "-I", str(INCLUDE), "-c", str(src), "-o", str(obj)]
+        obj = build_dir / (src.stem + ".o")
+        cmd = [hipcc, *FLAGS, *extra, *FILE_FLAGS.get(src.name, []), "-I", str(INCLUDE), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -68,14 +77,14 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 2)) as ex:
         objs = list(ex.map(compile_one, _sources()))
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(lib), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     stamp.write_text(fp)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    p = build_library(force="--force" in sys.argv, verbose=True)
+    p = build_library(force="--force" in sys.argv, verbose=True, ablation="--ablation" in sys.argv)
     print("built", p)

@@ -12,6 +12,7 @@
 #include "common.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
+#include <atomic>
 
 namespace cvx {
 
@@ -373,32 +374,35 @@ __global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restr
 
 using namespace cvx;
 
-int g_attn_variant = 0;     // cvx_set_option("attn_variant")
-int g_attn_xcd_remap = 1;   // cvx_set_option("attn_xcd_remap")
+std::atomic<int> g_attn_variant{0};     // cvx_set_option("attn_variant")
+std::atomic<int> g_attn_xcd_remap{1};   // cvx_set_option("attn_xcd_remap")
 
 extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
                                   int ntok, int ntp, int kp, hipStream_t st) {
     if (slices <= 0) return 0;
     if (ntp % 8 || kp % 64 || kp < ntok || ntp < ntok || ldqk % 8 || ldo % 4)
         return cvx_fail("attention: need ntp%8==0, kp%64==0, kp>=ntok, ntp>=ntok, ldqk%8==0");
-    const int rows_per_block = g_attn_variant == 4 ? 192 : g_attn_variant == 5 ? 256 : 128;
+    const int variant = g_attn_variant;  // one read per call: a concurrent cvx_set_option cannot give a mixed launch
+    const int rows_per_block = variant == 4 ? 192 : variant == 5 ? 256 : 128;
     const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;
     if (nblk > 0x7fffffff) return cvx_fail("attention: grid too large");
     const int xcd_remap = ((long)heads * slices) % 8 == 0 && g_attn_xcd_remap;
     dim3 grid((unsigned)nblk);
     void (*k)(const uint16_t*, long, const uint16_t*, uint16_t*, long, int, int, int, int, int, int, int);
-    switch (g_attn_variant) {
+    switch (variant) {
         case 1: k = k_attention<1>; break;
         case 3: k = k_attention<3>; break;
+#ifdef CVX_ABLATION  // timing-only, garbage output
         case 10: k = k_attention<10>; break;
         case 11: k = k_attention<11>; break;
         case 12: k = k_attention<12>; break;
         case 13: k = k_attention<13>; break;
+#endif
         default: k = k_attention<0>; break;
     }
-    if (g_attn_variant == 4 || g_attn_variant == 5) {
-        auto k64 = g_attn_variant == 4 ? k_attention64<3> : k_attention64<4>;
+    if (variant == 4 || variant == 5) {
+        auto k64 = variant == 4 ? k_attention64<3> : k_attention64<4>;
         hipLaunchKernelGGL(k64, grid, dim3(rows_per_block), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo,
                            heads, ntok, ntp, kp, heads * 64, nqb, xcd_remap);
         return cvx_check_launch();

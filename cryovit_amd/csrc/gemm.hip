@@ -4,6 +4,8 @@
 #include "gemm4w.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
+#include <atomic>
+#include <initializer_list>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(G256_THREADS) void k_gemm256_mreg(const uint16_t* A
 }
 
 // tuning switches (cvx_set_option): A/B the tile kernels and pipeline schedules inside ONE process
-static int g_use_gemm256 = 1, g_gemm256_variant = 5, g_gemm_stagger = 0;  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
+static std::atomic<int> g_use_gemm256{1}, g_gemm256_variant{5}, g_gemm_stagger{0};  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
 template <class Epi> static constexpr int epilogue_cycles() { return 12000; }       // bf16 store epilogues (stamped)
 template <> constexpr int epilogue_cycles<EpiResid>() { return 40000; }              // fp32 read-modify-write
 template <> constexpr int epilogue_cycles<EpiF32>() { return 20000; }
@@ -359,12 +361,14 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             case 6: k = k_gemm256_nreg<Epi, 6>; break;
             case 7: k = k_gemm256_nreg<Epi, 7>; break;
             case 8: k = k_gemm256_nreg<Epi, 8>; break;
+#ifdef CVX_ABLATION  // timing-only builds (stamps / garbage-output ablations): never in the product library
             case 20: k = k_gemm256_nreg<Epi, 20>; break;
             case 21: k = k_gemm256_nreg<Epi, 21>; break;
             case 10: k = k_gemm256_nreg<Epi, 10>; break;
             case 11: k = k_gemm256_nreg<Epi, 11>; break;
             case 12: k = k_gemm256_nreg<Epi, 12>; break;
             case 13: k = k_gemm256_nreg<Epi, 13>; break;
+#endif
             default: k = k_gemm256_nreg<Epi, 0>; break;
         }
     }
@@ -383,7 +387,7 @@ template <class E> struct epi_can_shift<E, std::void_t<decltype(std::declval<con
 // Tail split: a 256-tile grid whose last round would keep only a few CUs busy (e.g. 3096 tiles = 12 rounds + 24 tiles for
 // the N = 1536 GEMMs of one 128-slice batch) is cut into a main launch of whole rounds and a tail launch over the remaining
 // M rows with 128x128 tiles (4x as many, quarter-size tiles: the tail costs ~0.3 of a round instead of a full one).
-static int g_tail_split = 1;
+static std::atomic<int> g_tail_split{1};
 static long tail_split_rows(long M, long Npad, bool allow = true) {
     const long tiles_n = Npad / 256, tiles_m = (M + 255) / 256, tiles = tiles_n * tiles_m, rem = tiles % 256;
     if (!g_tail_split || !allow || tiles < 512 || rem == 0 || rem > 64) return M;
@@ -447,24 +451,40 @@ static int launch_conv3(const cvx_conv3d_desc& d, const Epi& epi, hipStream_t st
 
 using namespace cvx;
 
-extern int g_attn_variant, g_attn_xcd_remap;  // attention.hip
+extern std::atomic<int> g_attn_variant, g_attn_xcd_remap;  // attention.hip
 
 extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
     CVX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvx::g_gemm256_dbg), sizeof(unsigned long long) * 32));
     return 0;
 }
 
-static int g_conv_halo = 1;  // cvx_set_option("conv_halo", 0) forces the implicit-GEMM kernel (A/B runs, tests)
+static std::atomic<int> g_conv_halo{1};  // cvx_set_option("conv_halo", 0) forces the implicit-GEMM kernel (A/B runs, tests)
 
 extern "C" int cvx_set_option(const char* name, int value) {
     if (!name) return cvx_fail("set_option: null name");
-    if (!strcmp(name, "use_gemm256")) g_use_gemm256 = value;
-    else if (!strcmp(name, "gemm256_variant")) g_gemm256_variant = value;
-    else if (!strcmp(name, "gemm_stagger")) g_gemm_stagger = value;
-    else if (!strcmp(name, "gemm_tail_split")) g_tail_split = value;
-    else if (!strcmp(name, "conv_halo")) g_conv_halo = value;
-    else if (!strcmp(name, "attn_variant")) g_attn_variant = value;
-    else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value;
+    // Process-wide tuning defaults, read ONCE at the start of every launch call.  Every accepted value selects a kernel that
+    // computes the same result (parity-tested); the timing-only ablation kernels exist only in -DCVX_ABLATION builds.
+    auto one_of = [&](std::initializer_list<int> ok) { for (int v : ok) if (v == value) return true; return false; };
+#ifdef CVX_ABLATION
+    const bool abl = true;
+#else
+    const bool abl = false;
+#endif
+    if (!strcmp(name, "use_gemm256")) {
+        if (!one_of({0, 1, 2})) return cvx_fail("set_option: use_gemm256 must be 0, 1 or 2");
+        g_use_gemm256 = value;
+    } else if (!strcmp(name, "gemm256_variant")) {
+        if (!one_of({0, 1, 2, 5, 6, 7, 8}) && !(abl && one_of({10, 11, 12, 13, 20, 21})))
+            return cvx_fail("set_option: unknown gemm256_variant (ablation variants need a -DCVX_ABLATION build)");
+        g_gemm256_variant = value;
+    } else if (!strcmp(name, "gemm_stagger")) g_gemm_stagger = value != 0;
+    else if (!strcmp(name, "gemm_tail_split")) g_tail_split = value != 0;
+    else if (!strcmp(name, "conv_halo")) g_conv_halo = value != 0;
+    else if (!strcmp(name, "attn_variant")) {
+        if (!one_of({0, 1, 3, 4, 5}) && !(abl && one_of({10, 11, 12, 13})))
+            return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");
+        g_attn_variant = value;
+    } else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value != 0;
     else if (!strcmp(name, "tile_group_l")) {
         if (value < 1) return cvx_fail("set_option: tile_group_l must be >= 1");
         CVX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cvx::g_tile_group_l), &value, sizeof(int)));
@@ -504,6 +524,7 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
     const uint16_t* A = (const uint16_t*)d->a;
     const uint16_t* W = (const uint16_t*)d->w;
     if (d->m <= 0) return 0;
+    if (!A || !W || !d->out || !d->bias) return cvx_fail("gemm: a, w, out and bias must be device pointers");
     if (d->dtype != CVX_DTYPE_BF16 && d->dtype != CVX_DTYPE_F16) return cvx_fail("gemm: unknown dtype");
     if (d->dtype == CVX_DTYPE_F16 && d->epilogue != CVX_EPI_BF16 && d->epilogue != CVX_EPI_BF16_GELU && d->epilogue != CVX_EPI_CONVT)
         return cvx_fail("gemm: fp16 operands are built for the plain / GELU / ConvT epilogues (the segmentation head)");
@@ -531,10 +552,12 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
             return launch_nreg<TileCfg<128, 128, 2>>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_RESID: {
+            if (!d->out || !d->bias || !d->gamma) return cvx_fail("gemm: the residual epilogue needs out, bias and gamma (LayerScale)");
             EpiResid e{(float*)d->out, d->ldc, d->bias, d->gamma, d->m, d->n};
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_F32: {
+            if (!d->out || !d->bias || !d->gamma) return cvx_fail("gemm: the fp32 epilogue needs out, bias and gamma");
             EpiF32 e{(float*)d->out, d->ldc, d->bias, d->gamma, d->m, d->n};
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }

@@ -72,7 +72,7 @@ class HeadEngine:
         if not torch.cuda.is_available():
             raise ops._lib.CvxError("HeadEngine needs a HIP device (no CPU fallback)")
         ops._lib.load()
-        self.device = torch.device(device)
+        self.device = ops.norm_device(device)
         sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.widths = widths_from_state_dict(sd)
         c_in, blocks, c_tail = self.widths
@@ -169,7 +169,8 @@ class HeadEngine:
         ``probs`` / ``logits`` fp32 [D, 16h, 16w], ``dice_sums`` (fp32[3] device tensor) when labels are given and
         ``mask`` uint8 [D, 16h, 16w] = (probs >= mask_threshold) when a threshold is given.  ONE C call: cvx_head_forward."""
         c_in, blocks, _ = self.widths
-        ops._dev_check(feats_cl, labels)
+        if ops._dev_check(feats_cl, labels) != self.device:
+            raise ops._lib.CvxError(f"head: inputs live on {feats_cl.device}, the engine on {self.device}")
         if feats_cl.dtype != torch.float16 or feats_cl.numel() < ops.alloc_rows(D * h * w_) * c_in:
             raise ops._lib.CvxError("head: features must be fp16 [rup(D*h*w,256)+256 rows][c_in]")
         up = 2 ** len(blocks)
@@ -181,9 +182,9 @@ class HeadEngine:
         dice = torch.zeros(3, dtype=torch.float32, device=dev) if labels is not None else None
         if labels is not None and (labels.dtype != torch.int8 or tuple(labels.shape) != shape):
             raise ops._lib.CvxError(f"head: labels must be int8 {shape}")
-        check(ops._lib.load().cvx_head_forward(C.byref(self._desc), C.byref(self._make_ws(D, h, w_)), feats_cl.data_ptr(), D, h, w_,
-                                               ops._p(logits), ops._p(probs), ops._p(labels), ops._p(dice), ops._p(mask),
-                                               0.5 if mask_threshold is None else float(mask_threshold), ops._stream()), "cvx_head_forward")
+        ops.call(dev, "cvx_head_forward", ops._lib.load().cvx_head_forward, C.byref(self._desc), C.byref(self._make_ws(D, h, w_)),
+                 feats_cl.data_ptr(), D, h, w_, ops._p(logits), ops._p(probs), ops._p(labels), ops._p(dice), ops._p(mask),
+                 0.5 if mask_threshold is None else float(mask_threshold))
         return {"logits": logits, "probs": probs, "dice_sums": dice, "mask": mask}
 
     def _forward_py(self, feats_cl: torch.Tensor, D: int, h: int, w_: int, labels=None, want_logits=False, want_probs=True,

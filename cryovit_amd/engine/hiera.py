@@ -142,7 +142,7 @@ class HieraEngine:
         if not torch.cuda.is_available():
             raise ops._lib.CvxError("HieraEngine needs a HIP device (no CPU fallback)")
         ops._lib.load()
-        self.cfg, self.device = cfg, torch.device(device)
+        self.cfg, self.device = cfg, ops.norm_device(device)
         S = cfg.image_size
         self.grids = tuple(S // 4 // 2**i for i in range(len(cfg.stages)))
         self.plan, self.stage_ends = cfg.block_plan()

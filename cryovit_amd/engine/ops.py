@@ -1,7 +1,10 @@
 """Thin torch-tensor wrappers over the C ABI (``include/cryovit_hip.h``).
 
 torch is plumbing here: it owns device memory and the HIP stream; every arithmetic op below is a call into
-``libcryovit_hip.so``.  All wrappers launch on ``torch.cuda.current_stream()``.
+``libcryovit_hip.so``.  Every wrapper launches on the current stream OF THE DEVICE ITS TENSORS LIVE ON and makes that
+device the active HIP device for the duration of the C call (the library's ``hipFuncSetAttribute`` / launch calls act on
+the active device), so a rank of a multi-GPU launch never touches GPU 0 by accident.  Tensors on different devices in
+one call are rejected.
 """
 
 from __future__ import annotations
@@ -24,15 +27,26 @@ def alloc_rows(m: int) -> int:
     return round_up(m, ROW_PAD) + ROW_PAD
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def norm_device(device) -> torch.device:
+    """torch.device with an explicit index ("cuda" -> the active device), so it compares equal to ``tensor.device``."""
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise _lib.CvxError(f"cryovit_amd runs on HIP devices only, got {d}")
+    return d if d.index is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream(device=None) -> int:
+    """Raw hipStream_t of torch's current stream on `device` (default: the active device)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def _p(t) -> int | None:
     return None if t is None else t.data_ptr()
 
 
-def _dev_check(*ts) -> None:
+def _dev_check(*ts) -> torch.device:
+    """Validates the operands of one C call and returns the device they all live on."""
+    dev = None
     for t in ts:
         if t is None:
             continue
@@ -40,13 +54,26 @@ def _dev_check(*ts) -> None:
             raise _lib.CvxError("cryovit_amd ops need device (HIP) tensors; there is no CPU path")
         if not t.is_contiguous():  # the kernels index raw pointers: a strided view would be read as garbage
             raise _lib.CvxError(f"non-contiguous tensor {tuple(t.shape)} strides {t.stride()} passed to a HIP op")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise _lib.CvxError(f"operands of one HIP op live on different devices ({dev} and {t.device})")
+    if dev is None:
+        raise _lib.CvxError("HIP op called without any device tensor")
+    return dev
+
+
+def call(dev: torch.device, what: str, fn, *args) -> None:
+    """fn(*args, stream) with `dev` active and on `dev`'s current stream; raises CvxError on a non-zero status."""
+    with torch.cuda.device(dev):
+        check(fn(*args, _stream(dev)), what)
 
 
 def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, *, m: int, n: int,
          gamma=None, pos=None, npatch=0, ntp=0, tok0=0, heads=0, kp=0, H=0, W=0, cout=0, act=0, ldc=None) -> None:
     """C = A W^T with a fused epilogue.  a: bf16 [M_alloc, lda]; w: bf16 [n_pad, k_pad] (packed).  fp16 operands (both a and
     w) select the fp16 MFMA and fp16 outputs (plain / GELU / ConvT epilogues: the segmentation head)."""
-    _dev_check(a, w, out, bias, gamma, pos)
+    dev = _dev_check(a, w, out, bias, gamma, pos)
     assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and bias.dtype == torch.float32
     assert a.stride(-1) == 1 and w.is_contiguous() and bias.numel() >= w.shape[0]
     d = GemmDesc()
@@ -61,68 +88,67 @@ def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bia
     d.npatch, d.ntp, d.tok0, d.heads, d.kp = npatch, ntp, tok0, heads, kp
     d.H, d.W, d.cout, d.act = H, W, cout, act
     d.dtype = _lib.DTYPE_F16 if a.dtype == torch.float16 else _lib.DTYPE_BF16
-    check(_lib.load().cvx_gemm_bf16(C.byref(d), _stream()), "cvx_gemm_bf16")
+    call(dev, "cvx_gemm_bf16", _lib.load().cvx_gemm_bf16, C.byref(d))
 
 
 def conv3d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, zero_page: torch.Tensor, *, Cin: int,
            D: int, H: int, W: int, dil: int, cout: int, act: int) -> None:
-    _dev_check(x, w, bias, out, zero_page)
+    dev = _dev_check(x, w, bias, out, zero_page)
     d = Conv3dDesc()
     d.in_, d.w, d.bias, d.zero_page, d.out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), zero_page.data_ptr(), out.data_ptr()
     d.C, d.D, d.H, d.W, d.dil, d.cout = Cin, D, H, W, dil, cout
     d.n_pad, d.k_pad, d.act = w.shape[0], w.shape[1], act
-    check(_lib.load().cvx_conv3d_f16(C.byref(d), _stream()), "cvx_conv3d_f16")
+    call(dev, "cvx_conv3d_f16", _lib.load().cvx_conv3d_f16, C.byref(d))
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, rows: int, Cdim: int, eps: float) -> None:
-    _dev_check(x, w, b, out)
-    check(_lib.load().cvx_layernorm_bf16(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), out.data_ptr(), out.stride(0),
-                                         rows, Cdim, eps, _stream()), "cvx_layernorm_bf16")
+    dev = _dev_check(x, w, b, out)
+    call(dev, "cvx_layernorm_bf16", _lib.load().cvx_layernorm_bf16, x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(),
+         out.data_ptr(), out.stride(0), rows, Cdim, eps)
 
 
 def attention(qk: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, slices: int, heads: int, ntok: int, ntp: int,
               kp: int) -> None:
-    _dev_check(qk, vt, out)
-    check(_lib.load().cvx_attention_bf16(qk.data_ptr(), qk.stride(0), vt.data_ptr(), out.data_ptr(), out.stride(0), slices,
-                                         heads, ntok, ntp, kp, _stream()), "cvx_attention_bf16")
+    dev = _dev_check(qk, vt, out)
+    call(dev, "cvx_attention_bf16", _lib.load().cvx_attention_bf16, qk.data_ptr(), qk.stride(0), vt.data_ptr(), out.data_ptr(),
+         out.stride(0), slices, heads, ntok, ntp, kp)
 
 
 def preprocess_patches(slices: torch.Tensor, out: torch.Tensor) -> None:
-    _dev_check(slices, out)
+    dev = _dev_check(slices, out)
     assert slices.dim() == 3 and slices.is_contiguous() and slices.dtype in (torch.uint8, torch.float32)
     b, H, W = slices.shape
-    check(_lib.load().cvx_preprocess_patches(slices.data_ptr(), int(slices.dtype == torch.uint8), b, H, W, out.data_ptr(),
-                                             out.stride(0), _stream()), "cvx_preprocess_patches")
+    call(dev, "cvx_preprocess_patches", _lib.load().cvx_preprocess_patches, slices.data_ptr(), int(slices.dtype == torch.uint8),
+         b, H, W, out.data_ptr(), out.stride(0))
 
 
 def init_tokens(x: torch.Tensor, cls_pos0: torch.Tensor, reg: torch.Tensor, *, n_reg: int, slices: int, ntok: int, ntp: int,
                 Cdim: int) -> None:
-    _dev_check(x, cls_pos0, reg)
-    check(_lib.load().cvx_init_tokens(x.data_ptr(), x.stride(0), cls_pos0.data_ptr(), reg.data_ptr(), n_reg, slices, ntok, ntp,
-                                      Cdim, _stream()), "cvx_init_tokens")
+    dev = _dev_check(x, cls_pos0, reg)
+    call(dev, "cvx_init_tokens", _lib.load().cvx_init_tokens, x.data_ptr(), x.stride(0), cls_pos0.data_ptr(), reg.data_ptr(),
+         n_reg, slices, ntok, ntp, Cdim)
 
 
 def final_norm_features(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, *, slices: int, ntp: int, tok0: int,
                         hp: int, wp: int, Cdim: int, feats_f16, d_total: int, d0: int, feats_cl, tokens_f32=None) -> None:
-    _dev_check(x, w, b, feats_f16, feats_cl, tokens_f32)
-    check(_lib.load().cvx_final_norm_features(x.data_ptr(), x.stride(0), w.data_ptr(), b.data_ptr(), eps, slices, ntp, tok0, hp,
-                                              wp, Cdim, _p(feats_f16), d_total, d0, _p(feats_cl), _p(tokens_f32), _stream()),
-          "cvx_final_norm_features")
+    dev = _dev_check(x, w, b, feats_f16, feats_cl, tokens_f32)
+    call(dev, "cvx_final_norm_features", _lib.load().cvx_final_norm_features, x.data_ptr(), x.stride(0), w.data_ptr(),
+         b.data_ptr(), eps, slices, ntp, tok0, hp, wp, Cdim, _p(feats_f16), d_total, d0, _p(feats_cl), _p(tokens_f32))
 
 
 def im2col_patches(x: torch.Tensor, out: torch.Tensor) -> None:
-    _dev_check(x, out)
+    dev = _dev_check(x, out)
     assert x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32 and x.is_contiguous()
     b, _, Hi, Wi = x.shape
-    check(_lib.load().cvx_im2col_patches(x.data_ptr(), b, Hi, Wi, out.data_ptr(), out.stride(0), _stream()), "cvx_im2col_patches")
+    call(dev, "cvx_im2col_patches", _lib.load().cvx_im2col_patches, x.data_ptr(), b, Hi, Wi, out.data_ptr(), out.stride(0))
 
 
 def features_to_channels_last(feats_f16: torch.Tensor, out_cl: torch.Tensor) -> None:
-    _dev_check(feats_f16, out_cl)
+    dev = _dev_check(feats_f16, out_cl)
     Cdim = feats_f16.shape[0]
     nvox = feats_f16.numel() // Cdim
-    check(_lib.load().cvx_features_to_channels_last(feats_f16.data_ptr(), out_cl.data_ptr(), Cdim, nvox, _stream()),
-          "cvx_features_to_channels_last")
+    call(dev, "cvx_features_to_channels_last", _lib.load().cvx_features_to_channels_last, feats_f16.data_ptr(),
+         out_cl.data_ptr(), Cdim, nvox)
 
 
 def gn_stats_size(G: int) -> int:
@@ -131,11 +157,11 @@ def gn_stats_size(G: int) -> int:
 
 def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, stats: torch.Tensor, *, nvox: int,
               Cdim: int, G: int, eps: float) -> None:
-    _dev_check(x, w, b, out, stats)
+    dev = _dev_check(x, w, b, out, stats)
     if stats.dtype != torch.float32 or stats.numel() < gn_stats_size(G):
         raise _lib.CvxError(f"groupnorm: stats must be fp32 with >= {gn_stats_size(G)} elements (2*G*(1+CVX_GN_BLOCKS))")
-    check(_lib.load().cvx_groupnorm_f16(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), stats.data_ptr(), nvox, Cdim,
-                                         G, eps, _stream()), "cvx_groupnorm_f16")
+    call(dev, "cvx_groupnorm_f16", _lib.load().cvx_groupnorm_f16, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(),
+         stats.data_ptr(), nvox, Cdim, G, eps)
 
 
 _dice_scratch = {}
@@ -143,7 +169,7 @@ _dice_scratch = {}
 
 def dice_scratch(device) -> torch.Tensor:
     """Per (device, stream) partial-sum buffer of the fused output kernel (two volumes may be in flight on two streams)."""
-    key = (torch.device(device), _stream())
+    key = (torch.device(device), _stream(device))
     if key not in _dice_scratch:
         _dice_scratch[key] = torch.zeros(3 * _lib.DICE_BLOCKS, dtype=torch.float32, device=device)
     return _dice_scratch[key]
@@ -151,16 +177,16 @@ def dice_scratch(device) -> torch.Tensor:
 
 def conv3_out_fused(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs, labels, dice, *, D: int, H: int, W: int,
                     mask=None, mask_threshold: float = 0.5) -> None:
-    _dev_check(x, w, logits, probs, labels, dice, mask)
+    dev = _dev_check(x, w, logits, probs, labels, dice, mask)
     scratch = dice_scratch(x.device) if labels is not None else None
-    check(_lib.load().cvx_conv3_out_fused(x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), _p(labels), _p(dice),
-                                          _p(scratch), _p(mask), float(mask_threshold), D, H, W, _stream()), "cvx_conv3_out_fused")
+    call(dev, "cvx_conv3_out_fused", _lib.load().cvx_conv3_out_fused, x.data_ptr(), w.data_ptr(), float(bias), _p(logits),
+         _p(probs), _p(labels), _p(dice), _p(scratch), _p(mask), float(mask_threshold), D, H, W)
 
 
 def dice_sums(probs: torch.Tensor, labels: torch.Tensor, dice: torch.Tensor, thr: float = 0.5) -> None:
-    _dev_check(probs, labels, dice)
-    check(_lib.load().cvx_dice_sums(probs.data_ptr(), labels.data_ptr(), dice.data_ptr(), probs.numel(), thr, _stream()),
-          "cvx_dice_sums")
+    dev = _dev_check(probs, labels, dice)
+    call(dev, "cvx_dice_sums", _lib.load().cvx_dice_sums, probs.data_ptr(), labels.data_ptr(), dice.data_ptr(), probs.numel(),
+         thr)
 
 
 # ---- alternate encoder (SAM2 Hiera) ----
@@ -168,7 +194,7 @@ def dice_sums(probs: torch.Tensor, labels: torch.Tensor, dice: torch.Tensor, thr
 
 def sam_patches(src: torch.Tensor, out: torch.Tensor, *, S: int) -> None:
     """src: uint8 / float32 [D,H,W] (replicated to 3 channels) or float32 [D,3,H,W]; out bf16 [>= D*(S/4)^2, ld >= 147]."""
-    _dev_check(src, out)
+    dev = _dev_check(src, out)
     if src.dim() == 4:
         assert src.shape[1] == 3 and src.dtype == torch.float32
         mode, (D, _, H, W) = 2, src.shape
@@ -176,38 +202,39 @@ def sam_patches(src: torch.Tensor, out: torch.Tensor, *, S: int) -> None:
         assert src.dtype in (torch.uint8, torch.float32)
         mode, (D, H, W) = (0 if src.dtype == torch.uint8 else 1), src.shape
     assert out.dtype == torch.bfloat16 and out.shape[0] >= D * (S // 4) ** 2
-    check(_lib.load().cvx_sam_patches(src.data_ptr(), mode, D, H, W, S, out.data_ptr(), out.stride(0), _stream()), "cvx_sam_patches")
+    call(dev, "cvx_sam_patches", _lib.load().cvx_sam_patches, src.data_ptr(), mode, D, H, W, S, out.data_ptr(), out.stride(0))
 
 
 def window_attention(q: torch.Tensor, q_col: int, kv: torch.Tensor, k_col: int, v_col: int, out: torch.Tensor, *, slices: int,
                      heads: int, head_dim: int, grid: int, window: int, q_grid: int, q_window: int) -> None:
     """q / kv: bf16 row buffers; the q, k, v blocks start at the given columns (qkv GEMM output: 0, C, 2C)."""
-    _dev_check(q, kv, out)
+    dev = _dev_check(q, kv, out)
     assert q.dtype == kv.dtype == out.dtype == torch.bfloat16
     assert q.shape[0] >= slices * q_grid * q_grid and kv.shape[0] >= slices * grid * grid and out.shape[0] >= slices * q_grid * q_grid
     assert q_col + heads * head_dim <= q.shape[1] and max(k_col, v_col) + heads * head_dim <= kv.shape[1]
     assert heads * head_dim <= out.shape[1]
-    check(_lib.load().cvx_window_attention_bf16(q.data_ptr() + 2 * q_col, q.stride(0), kv.data_ptr() + 2 * k_col,
-                                                kv.data_ptr() + 2 * v_col, kv.stride(0), out.data_ptr(), out.stride(0), slices, heads,
-                                                head_dim, grid, window, q_grid, q_window, _stream()), "cvx_window_attention_bf16")
+    call(dev, "cvx_window_attention_bf16", _lib.load().cvx_window_attention_bf16, q.data_ptr() + 2 * q_col, q.stride(0),
+         kv.data_ptr() + 2 * k_col, kv.data_ptr() + 2 * v_col, kv.stride(0), out.data_ptr(), out.stride(0), slices, heads,
+         head_dim, grid, window, q_grid, q_window)
 
 
 def pool2x2(x: torch.Tensor, out: torch.Tensor, *, slices: int, grid: int, C: int) -> None:
-    _dev_check(x, out)
+    dev = _dev_check(x, out)
     assert x.dtype == out.dtype and x.dtype in (torch.float32, torch.bfloat16)
     assert x.shape[0] >= slices * grid * grid and out.shape[0] >= slices * (grid // 2) ** 2 and C <= min(x.shape[1], out.shape[1])
-    check(_lib.load().cvx_pool2x2(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), slices, grid, C,
-                                  int(x.dtype == torch.bfloat16), _stream()), "cvx_pool2x2")
+    call(dev, "cvx_pool2x2", _lib.load().cvx_pool2x2, x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), slices, grid, C,
+         int(x.dtype == torch.bfloat16))
 
 
 def cast_bf16(x: torch.Tensor, out: torch.Tensor, *, rows: int, C: int) -> None:
-    _dev_check(x, out)
+    dev = _dev_check(x, out)
     assert x.dtype == torch.float32 and out.dtype == torch.bfloat16 and min(x.shape[0], out.shape[0]) >= rows
-    check(_lib.load().cvx_cast_bf16(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, C, _stream()), "cvx_cast_bf16")
+    call(dev, "cvx_cast_bf16", _lib.load().cvx_cast_bf16, x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, C)
 
 
 def fpn_level_out(lateral: torch.Tensor, coarse, out: torch.Tensor, *, slices: int, C: int, grid: int) -> None:
-    _dev_check(lateral, coarse, out)
+    dev = _dev_check(lateral, coarse, out)
     assert lateral.dtype == torch.float32 and lateral.shape[1] == C and out.dtype == torch.float16
     assert out.numel() == slices * C * grid * grid and lateral.shape[0] >= slices * grid * grid
-    check(_lib.load().cvx_fpn_level_out(lateral.data_ptr(), _p(coarse), slices, C, grid, out.data_ptr(), _stream()), "cvx_fpn_level_out")
+    call(dev, "cvx_fpn_level_out", _lib.load().cvx_fpn_level_out, lateral.data_ptr(), _p(coarse), slices, C, grid,
+         out.data_ptr())

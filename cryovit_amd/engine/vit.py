@@ -121,7 +121,7 @@ class VitEngine:
         if not torch.cuda.is_available():
             raise ops._lib.CvxError("VitEngine needs a HIP device (no CPU fallback)")
         ops._lib.load()
-        self.cfg, self.device = cfg, torch.device(device)
+        self.cfg, self.device = cfg, ops.norm_device(device)
         self._pos_src = state_dict["pos_embed"].detach().float().cpu()
         self._cls = state_dict["cls_token"].detach().float().cpu().reshape(-1)
         self._ws = {}
@@ -221,6 +221,7 @@ class VitEngine:
     def _workspace(self, b: int, hp: int, wp: int):
         key = (b, hp, wp)
         if key in self._ws:
+            self._ws[key] = self._ws.pop(key)  # most recently used last
             return self._ws[key]
         cfg, dev = self.cfg, self.device
         _, _, nt, ntp, kp = self._geometry(hp, wp)
@@ -236,7 +237,11 @@ class VitEngine:
             "ao": z(rows, C),
             "hid": z(rows, self.hid_pad),
         }
-        self._ws = {key: ws}  # keep one shape resident
+        # keep the two most recent shapes resident: a tomogram whose depth is not a multiple of the slice batch alternates
+        # between the full batch and the remainder, and must not re-allocate and re-zero ~4 GB twice per tomogram
+        while len(self._ws) >= 2:
+            self._ws.pop(next(iter(self._ws)))
+        self._ws[key] = ws
         return ws
 
     # ---- forward ----------------------------------------------------------------------------------------------------
@@ -293,11 +298,11 @@ class VitEngine:
         cws = VitWs(x=ws["x"].data_ptr(), xn=ws["xn"].data_ptr(), qk=ws["qk"].data_ptr(), vt=ws["vt"].data_ptr(),
                     ao=ws["ao"].data_ptr(), hid=ws["hid"].data_ptr())
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-        for t in (ape, pe_w, feats_f16, feats_cl, tokens_f32):
-            ops._dev_check(t)
-        _lib.check(_lib.load().cvx_vit_encode(C.byref(self._c_desc()), C.byref(cws), b, hp, wp, ape.data_ptr(), ape.stride(0),
-                                              pe_w.data_ptr(), pos.data_ptr(), cls_pos0.data_ptr(), p(feats_f16), d_total, d0,
-                                              p(feats_cl), p(tokens_f32), ops._stream()), "cvx_vit_encode")
+        if ops._dev_check(ape, pe_w, feats_f16, feats_cl, tokens_f32, ws["x"]) != self.device:
+            raise _lib.CvxError(f"encoder: operands live on {ape.device}, the engine on {self.device}")
+        ops.call(self.device, "cvx_vit_encode", _lib.load().cvx_vit_encode, C.byref(self._c_desc()), C.byref(cws), b, hp, wp,
+                 ape.data_ptr(), ape.stride(0), pe_w.data_ptr(), pos.data_ptr(), cls_pos0.data_ptr(), p(feats_f16), d_total, d0,
+                 p(feats_cl), p(tokens_f32))
 
     def _encode_py(self, b, hp, wp, ape, pe_w, feats_f16, d_total, d0, feats_cl, tokens_f32) -> None:
         cfg = self.cfg

@@ -22,7 +22,7 @@ from cryovit_amd import io
 from cryovit_amd.config import instantiate, samples, tomogram_exts
 from cryovit_amd.models.encoder import load_encoder
 from cryovit_amd.models.sam_encoder import load_sam_encoder
-from cryovit_amd.run.sharding import shard_records, world_info
+from cryovit_amd.run.sharding import select_device, shard_records, world_info
 
 
 @torch.inference_mode()
@@ -35,7 +35,7 @@ def _dino_features(data: torch.Tensor, model, batch_size: int) -> np.ndarray:
         f16, _ = model.features_from_raw(data, batch_size, want_f16=True, want_cl=False)
         host = torch.empty(f16.shape, dtype=f16.dtype, pin_memory=True)  # pinned: the 403 MB D2H runs at PCIe speed
         host.copy_(f16, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        torch.cuda.current_stream(f16.device).synchronize()  # the copy runs on the stream of the TENSOR's device
         return host.numpy()
     hp, wp = data.shape[-2] // 14, data.shape[-1] // 14
     chunks = []
@@ -150,10 +150,7 @@ def run_trainer(cfg) -> None:
     sample = cfg.sample
     sample_names = [getattr(sample, "name", sample)] if sample is not None else [s for s in samples if (src_dir / s).exists()]
     enc = cfg.get("encoder", {}) or {}
-    _, local_rank, _ = world_info()
-    device = enc.get("device", "cuda:0")
-    if world_info()[2] > 1:
-        device = f"cuda:{local_rank}"
+    device = select_device(enc.get("device"))  # cuda:LOCAL_RANK under torch.distributed.run; sets the active device
     model = _load_model(cfg, enc, device)
     for sample_name in sample_names:
         _process_sample(src_dir, dst_dir, csv_dir, model, sample_name, cfg.datamodule, cfg.batch_size,
@@ -175,8 +172,8 @@ def run_dino(train_data: list[Path], result_dir: Path, batch_size: int, use_sam:
                   [f"batch_size={batch_size}", "sample=null", "export_features=False", "datamodule/dataset=file"])
     enc = dict(cfg.get("encoder", {}) or {})
     enc.update(encoder or {})
-    rank, local_rank, world = world_info()
-    device = f"cuda:{local_rank}" if world > 1 else enc.get("device", "cuda:0")
+    rank, _, world = world_info()
+    device = select_device(enc.get("device"))
     model = _load_model(cfg, enc, device)
     feature_fn = _sam_features if use_sam else _dino_features
     assert len(train_data) > 0, "No valid tomogram files found in the specified training data path."

@@ -15,6 +15,28 @@ def world_info() -> tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def select_device(requested: str | None = None) -> str:
+    """The HIP device of this rank, made the ACTIVE device of the process before anything is allocated.
+
+    Under ``torch.distributed.run`` (WORLD_SIZE > 1) that is ``cuda:LOCAL_RANK`` whatever the config says; launched plainly it
+    is ``requested`` (default ``cuda:0``).  Every later allocation, ``torch.cuda.current_stream()`` and every call into
+    ``libcryovit_hip.so`` (``hipFuncSetAttribute``, launches) then refers to this GPU and not to GPU 0."""
+    import torch
+
+    _, local_rank, world = world_info()
+    device = f"cuda:{local_rank}" if world > 1 else (requested or "cuda:0")
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise ValueError(f"cryovit_amd runs on HIP devices only, got {device!r}")
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible: cryovit_amd has no CPU path")
+    index = d.index if d.index is not None else 0
+    if index >= torch.cuda.device_count():
+        raise RuntimeError(f"rank wants cuda:{index} but only {torch.cuda.device_count()} device(s) are visible")
+    torch.cuda.set_device(index)
+    return f"cuda:{index}"
+
+
 def shard_records(records: list, rank: int, world: int, weights: list[float] | None = None) -> list[int]:
     """Indices of the records this rank owns.  With ``weights`` (e.g. D*H*W voxels) a size-sorted greedy assignment
     balances the load; otherwise round-robin.  Deterministic and identical on every rank."""

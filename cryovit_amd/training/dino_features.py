@@ -13,6 +13,7 @@ import traceback
 import warnings
 
 from cryovit_amd.config import CONFIG_DIR, compose, validate_dino_config
+from cryovit_amd.run.sharding import world_info
 
 warnings.simplefilter("ignore")
 logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s")
@@ -24,9 +25,11 @@ def _run(cfg) -> None:
     validate_dino_config(cfg)
     try:
         dino_features.run_trainer(cfg)
-    except BaseException as err:  # noqa: BLE001  (reference behaviour: log and continue)
-        logging.error("%s: %s", type(err).__name__, err)
+    except Exception as err:  # noqa: BLE001  (reference behaviour, l.33-37: log and continue; KeyboardInterrupt / SystemExit
+        logging.error("%s: %s", type(err).__name__, err)  # are NOT swallowed here)
         logging.error(traceback.format_exc())
+        if world_info()[2] > 1:  # a failed rank of a multi-GPU launch must be visible to the launcher
+            raise SystemExit(1) from err
 
 
 def main(argv: list[str] | None = None) -> None:

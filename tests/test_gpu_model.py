@@ -251,6 +251,84 @@ def test_vit_g_full_depth_one_slice_vs_oracle(gpu):
     _check_tokens(f16.float().cpu(), torch.from_numpy(ref.astype(np.float32)))
 
 
+def test_vit_g_headline_slice_vs_oracle(gpu):
+    """Oracle parity AT THE BENCHMARKED GEOMETRY (BASELINE configs[1]): ViT-g/14-reg, all 40 layers, one raw 512x512 uint8
+    slice -> fused resize to 448x448 -> N = 1029 tokens per slice (9 query blocks, 17 key tiles, the padded 1032/1088 row
+    and key counts of the real run), through ``VitEngine.features`` against
+      * the fp32 CPU oracle (reference call site /root/reference/src/cryovit/run/dino_features.py:53-61): max abs <= 1e-1,
+        mean abs <= 1e-2 on the fp16 ``dino_features`` values;
+      * the exact-arithmetic bf16-STORAGE emulation of the same network: what remains is the kernels' own contribution.
+    The slice sits at batch row 1 of 2 so its tokens straddle a 256-row GEMM tile boundary like the rows of a full batch."""
+    from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine, random_state_dict
+    from oracle import dinov2 as o
+    from oracle import preprocess as opre
+
+    cfg = VIT_CONFIGS["dinov2_vitg14_reg"]
+    sd_dev = random_state_dict(cfg, seed=2, device=gpu)
+    eng = VitEngine(cfg, sd_dev, gpu)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    del sd_dev
+    vol = np.random.default_rng(1).integers(0, 256, size=(2, 512, 512), dtype=np.uint8)
+    f16 = torch.zeros(1536, 2, 32, 32, dtype=torch.float16, device=gpu)
+    eng.features(torch.from_numpy(vol).to(gpu), feats_f16=f16, d_total=2, d0=0)
+    got = f16[:, 1].float().cpu().reshape(1536, 1024).t()  # [tokens, C] of slice 1
+    x = opre.dino_transform(opre.load_scale(vol[1:2]))  # [1,3,448,448]
+    assert tuple(x.shape) == (1, 3, 448, 448)
+    ref = o.forward_features(o.VITG14_REG, sd, x)["x_norm_patchtokens"][0]
+    assert ref.shape == (1024, 1536)
+    _check_tokens(got, ref.half().float())  # K9: the reference stores fp16 (run/dino_features.py:61)
+    emu = o.forward_features_bf16_storage(o.VITG14_REG, sd, x)["x_norm_patchtokens"][0]
+    e_emu, e_store = (got - emu).abs(), (emu - ref).abs()
+    # Over 40 layers two implementations of the SAME storage plan drift apart by about what either drifts from fp32 (every
+    # 1-ulp bf16 rounding flip is a perturbation of the storage plan's own size), so the bar for the kernels is: no further
+    # from the exact-arithmetic emulation than the emulation is from fp32.  Measured on MI355X: GPU vs emulation
+    # 0.035 max / 0.0062 mean, emulation vs fp32 0.044 / 0.0080.
+    assert float(e_emu.max()) <= 1.25 * float(e_store.max()) + 1e-2 and float(e_emu.mean()) <= float(e_store.mean()), (
+        float(e_emu.max()), float(e_emu.mean()), float(e_store.max()), float(e_store.mean()))
+    print(f"ViT-g N=1029: vs fp32 max {float((got - ref).abs().max()):.3e} mean {float((got - ref).abs().mean()):.3e}; "
+          f"vs bf16-storage emulation max {float(e_emu.max()):.3e} mean {float(e_emu.mean()):.3e}; "
+          f"emulation vs fp32 max {float(e_store.max()):.3e} mean {float(e_store.mean()):.3e}")
+
+
+def test_head_full_width_depth128_vs_oracle(gpu):
+    """Oracle parity at the benchmarked DEPTH (BASELINE configs[2]): the FULL-WIDTH head on features [1536, 128, 4, 4] ->
+    128 x 64 x 64 voxels.  At D = 128 every one of the eight depth dilations (32, 24, 16, 12, 8, 4, 2, 1 --
+    /root/reference/src/cryovit/models/cryovit.py:24-28) has voxels with BOTH z +- d taps inside the volume (D = 40 had none
+    for d = 32), and GroupNorm statistics span the real depth.  Logits vs the fp32 CPU oracle (max <= 5e-2, mean <= 5e-3),
+    masked Dice within 1e-3, and the number of labelled voxels within the logit tolerance of the threshold reported."""
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import HeadEngine
+    from oracle import dice as od
+    from oracle import head as oh
+    from oracle.make_golden import synth_labels
+
+    head = oh.CryoVITHead()
+    oh.rescaled_init_(head, seed=5)
+    C, D, h, w = 1536, 128, 4, 4
+    feats = torch.randn(C, D, h, w, generator=torch.Generator().manual_seed(3)).half()
+    with torch.inference_mode():
+        ref = head.forward_volume(feats.float().unsqueeze(0))[0, 0]
+    eng = HeadEngine(head.state_dict(), gpu)
+    cl = torch.zeros(ops.alloc_rows(D * h * w), C, dtype=torch.float16, device=gpu)
+    ops.features_to_channels_last(feats.to(gpu), cl)
+    labels = torch.from_numpy(synth_labels(D, 16 * h, 16 * w, seed=4))
+    out = eng.forward(cl, D, h, w, labels=labels.to(gpu), want_logits=True)
+    got = out["logits"].cpu()
+    assert tuple(got.shape) == (D, 16 * h, 16 * w)
+    err = (got - ref).abs()
+    assert float(err.max()) <= 5e-2 and float(err.mean()) <= 5e-3, (float(err.max()), float(err.mean()))
+    i, sy, sp = out["dice_sums"].cpu().tolist()
+    dice = 2 * i / (sy + sp + 1e-3)
+    want = od.dice_metric(torch.sigmoid(ref), labels.float())
+    near = int(((ref.abs() < 5e-2) & (labels > -1)).sum())
+    flips = int((((got > 0) != (ref > 0)) & (labels > -1)).sum())
+    assert abs(dice - want) <= 1e-3, (dice, want, f"{flips} flipped of {near} labelled voxels within 5e-2 of the threshold")
+    fg = float((ref > 0).float().mean())
+    assert 0.05 < fg < 0.95
+    print(f"head D=128: logits max err {float(err.max()):.3e} mean {float(err.mean()):.3e}; dice {dice:.5f} vs {want:.5f}; "
+          f"{flips} flips / {near} near-threshold labelled voxels")
+
+
 def test_full_size_properties(gpu):
     """BASELINE size (128x512x512, ViT-g + full-width head): properties that need no CPU oracle.
       * determinism: the ViT path has no atomics -> two runs give bit-identical fp16 features

@@ -6,7 +6,13 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os  # noqa: E402
+
+os.environ.setdefault("CVX_ABLATION_LIB", "1")  # the timing-only variants live in the -DCVX_ABLATION build only
 from cryovit_amd import _lib  # noqa: E402
+from cryovit_amd.build import build_library  # noqa: E402
+
+build_library(ablation=os.environ["CVX_ABLATION_LIB"] == "1")
 from cryovit_amd._lib import EPI_BF16, EPI_RESID, EPI_SWIGLU  # noqa: E402
 from cryovit_amd.engine import ops  # noqa: E402
 
