@@ -1,16 +1,23 @@
 """Headline benchmark: tomogram voxels/sec for (DINOv2 ViT-g/14-reg features + CryoVIT 3D-conv head forward + Dice).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one synthetic 128x512x512 tomogram (BASELINE.json configs[1]+[2] chained = the end-to-end unit of
 configs[3]) through the whole hot path on one GPU, input volume already resident in HBM.  Tomograms shard
-embarrassingly (SURVEY s.8e): every rank processes its own K tomograms, no data-path collective ("weak" scaling);
-RCCL is used only for the barrier and the MAX-over-ranks of the timed region.
+embarrassingly (SURVEY s.8e): every rank processes its own K tomograms (seeds 100 + rank*K + step: at N = 8, K = 4 these
+are configs[3]'s 32 tomograms, seeds 100..131, 4 per GPU), no data-path collective ("weak" scaling); RCCL is used only
+for the barrier and the MAX-over-ranks of the timed region.
+
+Launching.  ``python bench.py --gpus N`` with N > 1 is SELF-LAUNCHING: the parent process builds the library, touches no
+GPU, starts N child processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1),
+relays rank 0's JSON line and exits non-zero if any child fails.  Under ``python -m torch.distributed.run ... bench.py
+--gpus N`` (WORLD_SIZE already set) the process is one of the ranks and runs directly.
 
 The JSON line also carries
   roofline     -- the dominant kernel (the SwiGLU w12 GEMM, 44 % of all FLOPs): algorithmic FLOPs per launch divided
                   by its average launch duration measured live with HIP events on the launch stream
+  stages_ms    -- per-stage device time of ONE extra, untimed tomogram run op by op with HIP events between the launches
+                  (ViT GEMMs by kind / attention / LayerNorm / head ...): configs[1] = `vit_ms`, configs[2] = `head_ms`
   cpu_baseline -- the torch-CPU fp32 oracle timed on this box's host cores on a bounded sample (rank 0, N=1 only)
 """
 
@@ -20,22 +27,27 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
-
-import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 D_, H_, W_ = 128, 512, 512
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_TBS = 8.0
+N_TOMOGRAMS = 32  # configs[3]: seeds 100..131
+TRAFFIC_FILE = ROOT / "profiles" / "dominant_kernel_traffic.json"
 
 
 def synthetic_head_state_dict(seed: int, device) -> dict:
     """Variance-preserving synthetic init of the reference-layout head (PyTorch's default init gives an all-background
     prediction and a degenerate Dice == 0 -- SURVEY App. E)."""
+    import torch
+
     from cryovit_amd.engine.head import REF_WIDTHS
 
     g = torch.Generator(device=device).manual_seed(seed)
@@ -56,8 +68,10 @@ def synthetic_head_state_dict(seed: int, device) -> dict:
     return sd
 
 
-def synthetic_labels(device, seed: int) -> torch.Tensor:
+def synthetic_labels(device, seed: int):
     """int8 {-1,0,1}: z<16 and z>=112 unlabeled, one ellipsoid of foreground (SURVEY s.8d config 3)."""
+    import torch
+
     z = torch.arange(D_, device=device).view(-1, 1, 1).float()
     y = torch.arange(H_, device=device).view(1, -1, 1).float()
     x = torch.arange(W_, device=device).view(1, 1, -1).float()
@@ -69,12 +83,22 @@ def synthetic_labels(device, seed: int) -> torch.Tensor:
     return lab.contiguous()
 
 
+def synthetic_tomogram(device, seed: int):
+    """uint8 [128,512,512], uniform 0..254, generated on the device (BASELINE configs[1]/[3]: seeds 100..131)."""
+    import torch
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (torch.rand(D_, H_, W_, generator=g, device=device) * 255).to(torch.uint8)
+
+
 class DominantKernelTimer:
     """HIP-event timing of one GEMM epilogue kind on the stream the kernels are launched on, through the library's
     measurement hook (the encoder is ONE C call, cvx_vit_encode, so the events are recorded inside it)."""
 
     def __init__(self, lib_mod, epilogue: int, capacity: int = 4096):
         import ctypes as C
+
+        import torch
 
         self.lib, self.epi, self.cap, self.C = lib_mod, epilogue, capacity, C
         self.starts = [torch.cuda.Event(enable_timing=True) for _ in range(capacity)]
@@ -97,10 +121,84 @@ class DominantKernelTimer:
         return sum(self.starts[i].elapsed_time(self.stops[i]) for i in range(self.n)) / max(1, self.n)
 
 
+def stage_breakdown(vit, head, vol, labels, feats_cl, feats_f16, sb: int) -> dict:
+    """Device time per stage of ONE tomogram (outside the timed region): the same launch list as the product path, issued op
+    by op (``VitEngine._encode_py`` / ``HeadEngine._forward_py``) with a HIP event between consecutive launches on the launch
+    stream.  Kernel classes are told apart by the op wrapper that launched them."""
+    import torch
+
+    from cryovit_amd import _lib
+    from cryovit_amd.engine import ops
+
+    marks = []  # (label, event recorded AFTER the op)
+    names = {_lib.EPI_PATCH: "gemm_patch_embed", _lib.EPI_VT: "gemm_v", _lib.EPI_SWIGLU: "gemm_w12", _lib.EPI_BF16_GELU: "gemm_fc1"}
+
+    def ev(label):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((label, e))
+
+    wrapped = {}
+
+    def wrap(name, label_fn):
+        orig = getattr(ops, name)
+        wrapped[name] = orig
+
+        def f(*a, **k):
+            orig(*a, **k)
+            ev(label_fn(*a, **k))
+
+        setattr(ops, name, f)
+
+    def gemm_label(epi, a, w, *_, **k):
+        if epi in names:
+            return names[epi]
+        if epi == _lib.EPI_RESID:
+            return "gemm_proj" if w.shape[1] == vit.cfg.dim else "gemm_w3"
+        return "gemm_qk"
+
+    hp, wp = H_ // 16, W_ // 16
+    try:
+        wrap("gemm", gemm_label)
+        wrap("layernorm", lambda *a, **k: "layernorm")
+        wrap("attention", lambda *a, **k: "attention")
+        wrap("preprocess_patches", lambda *a, **k: "preprocess")
+        wrap("init_tokens", lambda *a, **k: "init_tokens")
+        wrap("final_norm_features", lambda *a, **k: "final_norm_features")
+        torch.cuda.synchronize()
+        ev("_start")
+        for d0 in range(0, D_, sb):
+            b = min(sb, D_ - d0)
+            ws = vit._workspace(b, hp, wp)
+            ape = ws["ape"].view(-1)[: ws["ape"].shape[0] * 256].view(-1, 256)
+            ops.preprocess_patches(vol[d0 : d0 + b], ape)
+            vit._encode_py(b, hp, wp, ape, vit.w["pe_w"], feats_f16, D_, d0, feats_cl[d0 * hp * wp :], None)
+    finally:
+        for name, orig in wrapped.items():
+            setattr(ops, name, orig)
+    head.forward(feats_cl, D_, hp, wp, labels=labels, want_probs=True)
+    ev("head")
+    torch.cuda.synchronize()
+    out: dict[str, float] = {}
+    for (_, e0), (label, e1) in zip(marks[:-1], marks[1:]):
+        out[label] = out.get(label, 0.0) + e0.elapsed_time(e1)
+    out["vit_ms"] = sum(v for k, v in out.items() if k != "head")
+    out["head_ms"] = out.pop("head")
+    return {k: round(v, 3) for k, v in out.items()}
+
+
 def cpu_baseline() -> dict:
-    """torch-CPU fp32 oracle on a bounded sample of the same workload (SURVEY s.8d 'CPU reference timing')."""
+    """torch-CPU fp32 oracle on a bounded sample of the same workload (SURVEY s.8d 'CPU reference timing'): ViT-g/14-reg on
+    k = 2 slices of 448x448, the head on [1,1536,128,8,8] (FULL depth, so dilation / padding / GroupNorm behave as in the real
+    volume; 1/16 of the in-plane extent), both extrapolated per voxel to 128x512x512, plus the whole T0 configuration
+    (64x256x256, ViT-S/14-reg, BASELINE configs[0]) un-extrapolated."""
+    import numpy as np
+    import torch
+
     from oracle import dinov2 as o
+    from oracle import features as ofe
     from oracle import head as oh
+    from oracle import preprocess as opre
 
     threads = torch.get_num_threads()
     cfg = o.VITG14_REG
@@ -111,27 +209,97 @@ def cpu_baseline() -> dict:
         for k, v in one.items():
             if k.startswith("blocks.0."):
                 sd[k.replace("blocks.0.", f"blocks.{i}.")] = v
-    x = torch.rand(1, 3, 448, 448)
+    k_slices = 2
+    x = torch.rand(k_slices, 3, 448, 448)
     t0 = time.perf_counter()
     o.forward_features(cfg, sd, x)
-    t_vit = time.perf_counter() - t0  # one 512x512 slice
+    t_vit = time.perf_counter() - t0
     head = oh.CryoVITHead()
     oh.rescaled_init_(head, seed=5)
-    d_s, h_s = 8, 4  # [1,1536,8,4,4] -> 8 x 64 x 64 output voxels
-    feats = torch.randn(1, 1536, d_s, h_s, h_s)
+    h_s = 8  # [1,1536,128,8,8] -> 128 x 128 x 128 output voxels
+    feats = torch.randn(1, 1536, D_, h_s, h_s)
     t0 = time.perf_counter()
     with torch.inference_mode():
         head.forward_volume(feats)
     t_head = time.perf_counter() - t0
-    s_per_voxel = t_vit / (H_ * W_) + t_head / (d_s * (16 * h_s) ** 2)
+    s_per_voxel = t_vit / (k_slices * H_ * W_) + t_head / (D_ * (16 * h_s) ** 2)
+    # T0, un-extrapolated: 64x256x256 uint8 -> resize -> ViT-S/14-reg -> fp16 [384,64,16,16]
+    vol0 = np.random.default_rng(0).integers(0, 256, size=(64, 256, 256), dtype=np.uint8)
+    sd_s = o.init_state_dict(o.VITS14_REG, seed=1)
+    t0 = time.perf_counter()
+    f0 = ofe.dino_features(opre.dino_transform(opre.load_scale(vol0)), o.OracleDino(o.VITS14_REG, sd_s), 64)
+    t_t0 = time.perf_counter() - t0
+    assert f0.shape == (384, 64, 16, 16)
     return {
         "value": 1.0 / s_per_voxel, "unit": "voxels/s", "cores": threads, "kind": "port",
-        "sample": f"oracle fp32: ViT-g/14-reg on 1 slice 448x448 ({t_vit:.1f} s) + head on [1,1536,{d_s},{h_s},{h_s}] "
-                  f"({t_head:.1f} s), extrapolated per voxel to 128x512x512; host has {os.cpu_count()} cpus",
+        "sample": f"oracle fp32, {threads} torch threads on {os.cpu_count()} host cpus: ViT-g/14-reg on {k_slices} slices 448x448 "
+                  f"({t_vit:.1f} s, x{D_ // k_slices} to 128 slices) + head on [1,1536,{D_},{h_s},{h_s}] ({t_head:.1f} s, x16 in-plane), "
+                  f"extrapolated per voxel to 128x512x512",
+        "t0_config": {"workload": "64x256x256 uint8, resize + ViT-S/14-reg features (configs[0]), whole run, not extrapolated",
+                      "seconds": round(t_t0, 2), "voxels_per_s": 64 * 256 * 256 / t_t0},
     }
 
 
-def main() -> None:
+def measured_traffic() -> dict:
+    """PMC traffic of the dominant kernel, per launch, from the committed rocprofv3 --pmc passes of this round (collected
+    with tools/profile_dominant.sh; `rocprofv3` cannot run inside this process)."""
+    if not TRAFFIC_FILE.exists():
+        return {"traffic": None}
+    t = json.loads(TRAFFIC_FILE.read_text())
+    return {
+        "traffic": t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"],
+        "traffic_fabric_fetch_bytes": t["fetch_bytes_per_launch"], "traffic_write_bytes": t["write_bytes_per_launch"],
+        "algorithmic_bytes": t["algorithmic_bytes_per_launch"],
+        "traffic_source": f"profiles/{TRAFFIC_FILE.name} (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 per the gfx950 correction: a "
+                          "fabric-side counter that INCLUDES Infinity-Cache hits, i.e. an upper bound on HBM bytes)",
+    }
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# launcher
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Parent of an N-GPU run: no HIP / torch.cuda call happens in this process.  One child per GPU; rank 0 inherits stdout
+    (its JSON line is the run's output), the other ranks' stdout goes to stderr.  Returns the exit code for the run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            code = p.poll()
+            if code not in (None, 0) and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                deadline = time.time() + 10
+                for q in procs:
+                    if q.poll() is None:
+                        q.terminate()  # the exact PIDs this launcher started
+        if deadline is not None and time.time() > deadline:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+        time.sleep(0.2)
+    for r, p in enumerate(procs):
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    return rc
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -139,18 +307,38 @@ def main() -> None:
     ap.add_argument("--slice-batch", type=int, default=128, help="slices per ViT launch sequence (reference default 128)")
     ap.add_argument("--streams", type=int, default=1, help="tomograms in flight per GPU, one per HIP stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-stages", action="store_true", help="skip the per-stage breakdown tomogram")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the launch / barrier / MAX-over-ranks / JSON plumbing over gloo (no GPU, no kernels)")
+    return ap.parse_args(argv)
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.dry_run:
+            from cryovit_amd.build import build_library
+
+            build_library()  # once, before the ranks start (hipcc needs no GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs MI355X devices"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+
+    if args.dry_run:
+        run_dry(args, rank, world, dist)
+        return
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs MI355X devices (use --dry-run for the CPU rehearsal of the launcher)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        import torch.distributed as dist
-
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm; only barrier + timing MAX use it
 
     from cryovit_amd import _lib
@@ -170,7 +358,9 @@ def main() -> None:
     head = HeadEngine(synthetic_head_state_dict(5, dev), dev)
     torch.cuda.empty_cache()
 
-    vol = (torch.rand(D_, H_, W_, generator=torch.Generator().manual_seed(100 + rank)) * 255).to(torch.uint8).to(dev)
+    K = args.steps
+    seeds = [100 + (rank * K + i) % N_TOMOGRAMS for i in range(max(K, 1))]
+    vols = [synthetic_tomogram(dev, s) for s in seeds]  # resident in HBM before the timed region (33.5 MB each)
     labels = synthetic_labels(dev, 4 + rank)
     hp, wp = H_ // 16, W_ // 16
     nvox_feat = D_ * hp * wp
@@ -191,7 +381,9 @@ def main() -> None:
     step_no = [0]
 
     def step():
-        c = ctxs[step_no[0] % S]
+        i = step_no[0]
+        c = ctxs[i % S]
+        vol = vols[i % len(vols)]
         step_no[0] += 1
         with torch.cuda.stream(c["stream"]):
             for d0 in range(0, D_, sb):
@@ -210,6 +402,7 @@ def main() -> None:
     kt = DominantKernelTimer(_lib, EPI_SWIGLU)
     for _ in range(args.warmup):
         out = step()
+    step_no[0] = 0
     sync_all()
     kt.start()
     t0 = time.perf_counter()
@@ -224,40 +417,95 @@ def main() -> None:
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed_max = float(t.item())
     i, sy, sp = out["dice_sums"].cpu().tolist()
     fg = float((out["probs"] >= 0.5).float().mean())
+    voxels = D_ * H_ * W_
+    per_rank = None
+    if world > 1:  # every rank's own rate (its K tomograms / its own time), gathered on rank 0 for the line
+        rates = [None] * world
+        dist.all_gather_object(rates, args.steps * voxels / elapsed)
+        per_rank = [float(r) for r in rates]
 
     if rank == 0:
-        voxels = D_ * H_ * W_
-        value = world * args.steps * voxels / elapsed
+        value = world * args.steps * voxels / elapsed_max
         rows = min(sb, D_) * (hp * wp + 1 + cfg.n_reg)  # valid tokens per launch
         k_flops = 2.0 * rows * cfg.dim * 2 * cfg.ffn_hidden
         achieved = k_flops / (k_ms * 1e-3) / 1e12
         flops_tomo = vit.flops(D_, H_, W_) + head.flops(D_, hp, wp)
-        traffic = None
-        tf = ROOT / "profiles" / "dominant_kernel_traffic.json"
-        if tf.exists():
-            traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
         line = {
             "metric": "tomogram voxels/sec (DINO feats + 3D seg fwd)", "value": value, "unit": "voxels/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "one 128x512x512 uint8 tomogram per step per GPU: fused resize + DINOv2 ViT-g/14-reg "
-                                   "(40 layers, N=1029 tokens/slice) -> fp16 dino_features [1536,128,32,32] + CryoVIT head "
-                                   "[1,1536,128,32,32] -> probs [128,512,512] + masked Dice; synthetic weights",
+            "config": {"workload": "one 128x512x512 uint8 tomogram per step per GPU (configs[3]'s seeds 100..131, rank r takes "
+                                   "100 + r*steps + i): fused resize + DINOv2 ViT-g/14-reg (40 layers, N=1029 tokens/slice) -> fp16 "
+                                   "dino_features [1536,128,32,32] + CryoVIT head [1,1536,128,32,32] -> probs [128,512,512] + masked "
+                                   "Dice; synthetic weights",
                        "slice_batch": sb, "streams": args.streams, "parallelism": f"tomogram-sharded x{world}, no collectives"},
-            "tflops_end_to_end": flops_tomo * world * args.steps / elapsed / 1e12,
-            "frac_of_mfma_peak_end_to_end": flops_tomo * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS,
+            "tflops_end_to_end": flops_tomo * world * args.steps / elapsed_max / 1e12,
+            "frac_of_mfma_peak_end_to_end": flops_tomo * args.steps / elapsed_max / 1e12 / PEAK_BF16_TFLOPS,
             "dice": 2 * i / (sy + sp + 1e-3), "pred_fg_fraction": fg,
-            "roofline": {"bound": "mfma", "kernel": "k_gemm256_nreg<EpiSwiGLU,5> (w12 GEMM 1536->8192 + fused SiLU gate)", "achieved": achieved,
-                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": "k_gemm256 w12 GEMM 1536->8192 + fused SiLU gate (EpiSwiGLU)", "achieved": achieved,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, **measured_traffic(),
                          "launches_timed": n_launch, "avg_launch_ms": k_ms, "flops_per_launch": k_flops},
         }
+        if per_rank is not None:
+            line["per_rank_voxels_per_s"] = per_rank
+        if not args.no_stages:
+            st = stage_breakdown(vit, head, vols[0], labels, feats_cl, feats_f16, sb)
+            line["stages_ms"] = st
+            head_bytes = 402.65e6 + 134.2e6 + 33.6e6 + 16.8e6  # SURVEY s.8d: compulsory HBM bytes of configs[2]
+            line["configs"] = {
+                "configs[1] ViT-g features, one tomogram": {"ms": st["vit_ms"], "voxels_per_s": voxels / st["vit_ms"] * 1e3,
+                                                            "tflops": vit.flops(D_, H_, W_) / st["vit_ms"] / 1e9},
+                "configs[2] head fwd + Dice": {"ms": st["head_ms"], "voxels_per_s": voxels / st["head_ms"] * 1e3,
+                                               "tflops": head.flops(D_, hp, wp) / st["head_ms"] / 1e9,
+                                               "compulsory_GBps": head_bytes / st["head_ms"] / 1e6, "hbm_peak_GBps": PEAK_HBM_TBS * 1e3},
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_dry(args, rank: int, world: int, dist) -> None:
+    """The multi-rank plumbing without a GPU: gloo rendezvous on 127.0.0.1, per-rank shard of the 32 tomogram seeds, barrier
+    on both sides of a timed region, MAX over ranks, one JSON line from rank 0."""
+    import torch
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    K = args.steps
+    seeds = [100 + (rank * K + i) % N_TOMOGRAMS for i in range(K)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    acc = 0
+    for s in seeds:  # stand-in "step": deterministic host work per tomogram seed
+        acc += int(torch.randint(0, 256, (64, 64), generator=torch.Generator().manual_seed(s)).sum())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    all_seeds = [None] * world
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_gather_object(all_seeds, seeds)
+    else:
+        all_seeds = [seeds]
+    if rank == 0:
+        voxels = D_ * H_ * W_
+        print(json.dumps({"metric": "tomogram voxels/sec (DINO feats + 3D seg fwd)", "value": world * K * voxels / float(t.item()),
+                          "unit": "voxels/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": float(t.item()) / K * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "dry-run (no GPU work)",
+                          "config": {"workload": "launcher rehearsal", "seeds_per_rank": all_seeds}}), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

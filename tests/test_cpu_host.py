@@ -231,3 +231,56 @@ def test_sam_feature_file_layout_and_config(tmp_path):
             assert got.dtype == np.float16 and np.array_equal(got, a)
     assert np.array_equal(io.read_dataset(out, "dino_features"), data["dino_features"])
     assert np.array_equal(io.read_dataset(out, "labels/mito"), data["mito"])
+
+
+def test_ops_reject_host_and_mixed_device_operands():
+    """The op wrappers launch on the stream of the device their operands live on: host tensors (no CPU path) and operands
+    spread over two devices are refused before any C call (ranks >= 1 must never fall through to GPU 0)."""
+    import pytest
+    import torch
+
+    from cryovit_amd._lib import CvxError
+    from cryovit_amd.engine import ops
+
+    with pytest.raises(CvxError, match="no CPU path"):
+        ops._dev_check(torch.zeros(4))
+
+    class FakeDev:  # stands in for a device tensor (no GPU in the CPU suite)
+        is_cuda = True
+
+        def __init__(self, index):
+            self.device, self.shape = torch.device("cuda", index), (4,)
+
+        def is_contiguous(self):
+            return True
+
+    assert ops._dev_check(FakeDev(1), None, FakeDev(1)) == torch.device("cuda", 1)
+    with pytest.raises(CvxError, match="different devices"):
+        ops._dev_check(FakeDev(0), FakeDev(1))
+    with pytest.raises(CvxError, match="without any device tensor"):
+        ops._dev_check(None)
+
+
+def test_select_device_follows_local_rank(monkeypatch):
+    """Under torch.distributed.run the rank's device is cuda:LOCAL_RANK whatever the config asks for; it must be made the
+    ACTIVE device (set_device) before anything is allocated."""
+    import torch
+
+    from cryovit_amd.run import sharding
+
+    calls = []
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: calls.append(i))
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setenv("RANK", "5")
+    assert sharding.select_device("cuda:0") == "cuda:5" and calls == [5]
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert sharding.select_device("cuda:2") == "cuda:2" and calls == [5, 2]
+    assert sharding.select_device(None) == "cuda:0"
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    import pytest
+
+    with pytest.raises(RuntimeError, match="only 1 device"):
+        sharding.select_device("cuda:3")
