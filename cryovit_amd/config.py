@@ -116,8 +116,11 @@ def _resolve(root: dict, node):
             if not m:
                 break
             cur: Any = root
+            ref = m.group(1)
+            if ref.startswith("hydra:runtime.choices."):  # the option selected for a config group (model=cryovit -> "cryovit")
+                ref = "__choices__." + ref.removeprefix("hydra:runtime.choices.")
             try:
-                for part in m.group(1).split("."):
+                for part in ref.split("."):
                     cur = cur[part]
             except (KeyError, TypeError):
                 break  # OmegaConf resolves lazily: a dangling reference only matters if somebody reads the key
@@ -145,13 +148,16 @@ def compose(config_name: str, overrides: list[str] | None = None) -> Cfg:
         else:
             sets.append((key, val))
     cfg = _load(config_name, choices)
+    cfg["__choices__"] = dict(choices)
     for key, val in sets:
         node = cfg
         parts = key.split(".")
         for p in parts[:-1]:
             node = node.setdefault(p, {})
         node[parts[-1]] = yaml.safe_load(val) if val != "" else ""
-    return _wrap(_resolve(cfg, cfg))
+    cfg = _resolve(cfg, cfg)
+    del cfg["__choices__"]
+    return _wrap(cfg)
 
 
 def missing_keys(cfg, prefix="") -> list[str]:
@@ -174,6 +180,26 @@ def validate_dino_config(cfg) -> None:
         sys.exit(1)
 
 
+def validate_experiment_config(cfg) -> None:
+    """config.py:234-286: missing parameters, then sample names outside the ``Sample`` enum -> logged, exit 1; a single
+    sample string becomes a one-element list."""
+    miss = missing_keys(cfg)
+    if miss:
+        logging.error("\n".join(["The following parameters were missing from config:"] + [f"{i}. {k}" for i, k in enumerate(miss, 1)]))
+        sys.exit(1)
+    dm = cfg.datamodule
+    if isinstance(dm.sample, str):
+        dm.sample = [dm.sample]
+    if isinstance(dm.get("test_sample"), str):
+        dm.test_sample = [dm.test_sample]
+    invalid = [s for s in dm.sample if s not in samples]
+    if isinstance(dm.get("test_sample"), list):
+        invalid += [s for s in dm.test_sample if s not in samples]
+    if invalid:
+        logging.error("\n".join(["The following datamodule parameters are not valid samples:"] + [f"{i}. {s}" for i, s in enumerate(invalid, 1)]))
+        sys.exit(1)
+
+
 def instantiate(node, **kwargs):
     """``hydra.utils.instantiate`` for ``_target_`` / ``_partial_`` nodes (the reference's plug-in mechanism)."""
     node = dict(node)
@@ -181,6 +207,11 @@ def instantiate(node, **kwargs):
     is_partial = bool(node.pop("_partial_", False))
     mod, _, attr = target.rpartition(".")
     fn = getattr(importlib.import_module(mod), attr)
-    args = {k: (instantiate(v) if isinstance(v, dict) and "_target_" in v else v) for k, v in node.items()}
+    def build(v):  # Hydra instantiates nested ``_target_`` nodes at any depth (e.g. model.metrics.dice_metric)
+        if isinstance(v, dict):
+            return instantiate(v) if "_target_" in v else {k: build(x) for k, x in v.items()}
+        return [build(x) for x in v] if isinstance(v, list) else v
+
+    args = {k: build(v) for k, v in node.items()}
     args.update(kwargs)
     return partial(fn, **args) if is_partial else fn(**args)

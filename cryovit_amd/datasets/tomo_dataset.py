@@ -1,7 +1,8 @@
 """Loader feeding the segmentation head (mirror of the inference half of
-``/root/reference/src/cryovit/datasets/tomo_dataset.py:89-146`` and ``datamodules/utils.py:13-121``).
+``/root/reference/src/cryovit/datasets/tomo_dataset.py:16-146`` and ``datamodules/utils.py:13-121``).
 
-Training-only behaviour (random crops, l.148-178) is out of scope.
+Training-only behaviour (the random crop of l.148-178) belongs to SURVEY s.8f row N4 and is not built: ``train=True`` is
+refused.
 """
 
 from __future__ import annotations
@@ -13,54 +14,110 @@ import torch
 from torch.utils.data import Dataset
 
 from cryovit_amd import io
-from cryovit_amd.types import BatchedTomogramData, TomogramData
+from cryovit_amd.types import BatchedTomogramData, BatchedTomogramMetadata, TomogramData
+
+
+def _as_records(records) -> list[dict]:
+    """A pandas DataFrame (the reference's type), a list of dicts (csv rows) or of (sample, tomo_name) pairs."""
+    if hasattr(records, "to_dict"):
+        return records.to_dict("records")
+    out = []
+    for r in records:
+        out.append(dict(r) if isinstance(r, dict) else {"sample": r[0], "tomo_name": r[1]})
+    return out
 
 
 class TomoDataset(Dataset):
-    """records: list of (sample, tomo_name); reads ``input_key`` (default ``dino_features``) and ``labels/<label_key>``."""
+    """One item per record (``sample``, ``tomo_name`` [, ``<split_key>``]): ``<data_root>/<sample>/<tomo_name>`` holds
+    ``<input_key>`` (``dino_features`` fp16 [C,D,h,w], or a raw [D,H,W] volume), ``labels/<label_key>`` and optional
+    auxiliary datasets (``aux_keys``, e.g. ``data``; keys absent from the file are skipped like upstream)."""
 
-    def __init__(self, records, input_key: str, label_key: str, data_root, aux_keys=(), **_):
-        self.records = list(records)
-        self.input_key, self.label_key, self.aux_keys = input_key, label_key, list(aux_keys)
+    def __init__(self, records, input_key: str, label_key: str, split_key: str | None = "split_id", data_root=".", aux_keys=None,
+                 train: bool = False) -> None:
+        if train:
+            raise NotImplementedError("TomoDataset(train=True): the training-side random crop is out of scope of this build")
+        self.records = _as_records(records)
+        self.input_key, self.label_key, self.split_key = input_key, label_key, split_key
+        self.aux_keys = list(aux_keys or [])
         self.data_root = Path(data_root)
+        self.train = train
 
     def __len__(self) -> int:
         return len(self.records)
 
     def __getitem__(self, idx: int) -> TomogramData:
-        sample, tomo_name = self.records[idx]
-        return self._load_tomogram(sample, tomo_name)
+        if idx >= len(self):
+            raise IndexError
+        record = self.records[idx]
+        data = self._load_tomogram(record)
+        return TomogramData(sample=record["sample"], tomo_name=record["tomo_name"], split_id=data.get("split_id"),
+                            data=torch.from_numpy(np.ascontiguousarray(data["input"])),
+                            label=torch.from_numpy(np.ascontiguousarray(data["label"])),
+                            aux_data={k: data[k] for k in self.aux_keys if k in data})
 
-    def _load_tomogram(self, sample: str, tomo_name: str) -> TomogramData:
-        path = self.data_root / sample / tomo_name
+    def _load_tomogram(self, record: dict) -> dict:
+        """tomo_dataset.py:89-146: uint8 input scaled to [0,1], a 3-D input gets a channel axis, labels as stored."""
+        path = self.data_root / record["sample"] / record["tomo_name"]
+        out = {"sample": record["sample"], "tomo_name": record["tomo_name"]}
+        if self.split_key is not None and record.get(self.split_key) not in (None, ""):
+            out["split_id"] = int(float(record[self.split_key]))
+        top = io.list_keys(path, "/")
+        assert self.input_key in top, f"Input key '{self.input_key}' not found in {path}."
+        assert "labels" in top and self.label_key in io.list_keys(path, "labels"), f"Label key '{self.label_key}' not found in {path}/labels."
         data = io.read_dataset(path, self.input_key)
-        if data.dtype == np.uint8:  # tomo_dataset.py: raw input is scaled, features pass through
+        if data.dtype == np.uint8:
             data = data.astype(np.float32) / 255.0
         if data.ndim == 3:
-            data = data[np.newaxis]
-        label = io.read_dataset(path, f"labels/{self.label_key}")
-        aux = {k: io.read_dataset(path, k) for k in self.aux_keys}
-        return TomogramData(sample=sample, tomo_name=tomo_name, data=torch.from_numpy(np.ascontiguousarray(data)),
-                            label=torch.from_numpy(np.ascontiguousarray(label)), aux_data=aux)
+            data = data[np.newaxis]  # channel axis
+        out["input"] = data
+        out["label"] = io.read_dataset(path, f"labels/{self.label_key}")
+        for key in self.aux_keys:
+            if key == "sam_features":
+                raise NotImplementedError("cached SAM2 features as aux data feed the SAM2 video model, which is out of scope")
+            node, ok = "/", True
+            for part in key.split("/"):  # "data", "labels/mito"
+                if part not in io.list_keys(path, node):
+                    ok = False
+                    break
+                node = part if node == "/" else f"{node}/{part}"
+            if ok:
+                out[key] = io.read_dataset(path, key)
+        return out
 
 
 def collate_fn(batch: list[TomogramData]) -> BatchedTomogramData:
-    """Stack tomograms: depth padded to the longest (data 0, label -1), cast to fp32, ``[B,D,C,h,w]``
-    (datamodules/utils.py:13-121; the reference's B>1 label-padding quirk, SURVEY App. D-4, is not reproduced)."""
-    dmax = max(t.data.shape[1] for t in batch)
-    datas, labels = [], []
-    for t in batch:
-        d = t.data.float()
-        lab = t.label.float()
-        pad = dmax - d.shape[1]
-        if pad:
-            d = torch.nn.functional.pad(d, (0, 0, 0, 0, 0, pad), value=0.0)
-            lab = torch.nn.functional.pad(lab, (0, 0, 0, 0, 0, pad), value=-1.0)
-        datas.append(d.permute(1, 0, 2, 3))
-        labels.append(lab)
-    return BatchedTomogramData(
-        tomo_batch=torch.stack(datas), labels=torch.stack(labels),
-        tomo_sizes=torch.tensor([t.data.shape[1] for t in batch]), min_slices=min(t.data.shape[1] for t in batch),
-        metadata={"samples": [t.sample for t in batch], "tomo_names": [t.tomo_name for t in batch]},
-        aux_data={k: [t.aux_data[k] for t in batch] for k in batch[0].aux_data} if batch[0].aux_data else None,
-    )
+    """Stack tomograms: depth padded to the longest (data 0, label -1), cast to fp32, ``[B,C,D,h,w] -> [B,D,C,h,w]``, metadata
+    as index pairs into the distinct samples / names (datamodules/utils.py:13-121).  The reference pads the LABEL of a
+    shorter tomogram with a padded copy of its DATA (l.83-85): that is a bug, not a contract, and only
+    triggers for B > 1 with unequal depths (evaluation uses B = 1); here the label is padded with -1 = ignore."""
+    sizes = torch.tensor([t.data.shape[-3] for t in batch], dtype=torch.int)
+    dmax = int(sizes.max())
+    C, _, hp, wp = batch[0].data.shape
+    H, W = batch[0].label.shape[-2:]
+    tomo_batch = torch.empty(len(batch), C, dmax, hp, wp, dtype=torch.float)
+    labels = torch.empty(len(batch), dmax, H, W, dtype=torch.float)
+    aux: dict[str, list] = {k: [] for k in (batch[0].aux_data or {})}
+    samples: dict[str, None] = {}
+    names: dict[str, None] = {}
+    ident = torch.empty(len(batch), 2, dtype=torch.long)
+    split = torch.empty(len(batch), dtype=torch.int)
+    use_splits = True
+    for i, t in enumerate(batch):
+        d = int(sizes[i])
+        tomo_batch[i, :, :d] = t.data
+        labels[i, :d] = t.label.reshape(-1, H, W)[:d] if t.label.dim() == 4 else t.label
+        if d < dmax:
+            tomo_batch[i, :, d:] = 0.0
+            labels[i, d:] = -1.0
+        for k, v in (t.aux_data or {}).items():
+            aux[k].append(v)
+        samples[t.sample] = None
+        names[t.tomo_name] = None
+        ident[i, 0], ident[i, 1] = list(samples).index(t.sample), list(names).index(t.tomo_name)
+        if t.split_id is not None and use_splits:
+            split[i] = t.split_id
+        else:
+            use_splits = False
+    meta = BatchedTomogramMetadata(samples=list(samples), tomo_names=list(names), unique_id=ident, split_id=split if use_splits else None)
+    return BatchedTomogramData(tomo_batch=tomo_batch.permute(0, 2, 1, 3, 4), labels=labels, tomo_sizes=sizes,
+                               min_slices=int(sizes.min()), metadata=meta, aux_data=aux or None)

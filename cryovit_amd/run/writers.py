@@ -73,3 +73,30 @@ def update_metrics_csv(results_dir, sample: str, tomo_name: str, metrics: dict[s
         for r in rows:
             w.writerow(r)
     return path
+
+
+class TestPredictionWriter:
+    """Callback form of ``write_test_prediction`` (callbacks.py:15-58): the ``_target_`` of ``configs/callbacks/test_pred_writer.yaml``."""
+
+    __test__ = False  # not a pytest class
+
+    def __init__(self, results_dir, label_key: str, **_):
+        self.results_dir, self.label_key = Path(results_dir), label_key
+
+    def on_test_batch_end(self, trainer, pl_module, outputs, batch=None, batch_idx: int = 0, dataloader_idx: int = 0) -> None:
+        for n in range(outputs.num_tomos):
+            write_test_prediction(self.results_dir, outputs.samples[n], outputs.tomo_names[n], self.label_key, outputs.data[n],
+                                  outputs.label[n], outputs.preds[n])
+
+
+class CsvWriter:
+    """Callback form of ``update_metrics_csv`` (callbacks.py:112-206): one row per tomogram in ``<sample>[_<split>].csv``."""
+
+    def __init__(self, results_dir, **_):
+        self.results_dir = Path(results_dir)
+        self.results_dir.mkdir(parents=True, exist_ok=True)
+
+    def on_test_batch_end(self, trainer, pl_module, outputs, batch=None, batch_idx: int = 0, dataloader_idx: int = 0) -> None:
+        assert outputs.num_tomos == 1, "CsvWriter only supports single-tomogram batches."
+        split_id = outputs.split_id[0] if outputs.split_id is not None else None
+        update_metrics_csv(self.results_dir, outputs.samples[0], outputs.tomo_names[0], outputs.metrics, split_id)

@@ -53,6 +53,22 @@ class TomogramData:
     data: torch.Tensor
     label: torch.Tensor
     aux_data: dict[str, Any] = field(default_factory=dict)
+    split_id: int | None = None
+
+
+@dataclass
+class BatchedTomogramMetadata:
+    """Who is in a batch (types.py:102-123): the distinct samples / file names and, per tomogram, its (sample index, name
+    index) pair; ``split_id`` only when every tomogram of the batch carries one."""
+
+    samples: list[str]
+    tomo_names: list[str]
+    unique_id: torch.Tensor  # long [B,2]
+    split_id: torch.Tensor | None = None  # int [B]
+
+    @property
+    def identifiers(self) -> tuple[list[str], list[str]]:
+        return ([self.samples[int(i[0])] for i in self.unique_id], [self.tomo_names[int(i[1])] for i in self.unique_id])
 
 
 @dataclass
@@ -63,21 +79,26 @@ class BatchedTomogramData:
     labels: torch.Tensor
     tomo_sizes: torch.Tensor
     min_slices: int = 0
-    metadata: dict[str, Any] = field(default_factory=dict)
+    metadata: BatchedTomogramMetadata | None = None
     aux_data: dict[str, Any] | None = None
 
     @property
     def num_tomos(self) -> int:
         return int(self.tomo_batch.shape[0])
 
+    @property
+    def num_slices(self) -> int:
+        return int(self.tomo_batch.shape[1])
+
 
 @dataclass
 class BatchedModelResult:
-    """Per-batch evaluation result (types.py:192-219)."""
+    """Per-batch evaluation result, organised per tomogram (types.py:192-219): what ``test_step`` hands to the writers."""
 
     num_tomos: int
     samples: list[str]
     tomo_names: list[str]
+    split_id: list[int] | None
     data: list[np.ndarray]
     label: list[np.ndarray]
     preds: list[np.ndarray]

@@ -105,7 +105,7 @@ def test_collate_fn_layout():
     b = collate_fn([t, u])
     assert tuple(b.tomo_batch.shape) == (2, 5, 16, 2, 3) and b.tomo_batch.dtype == torch.float32
     assert tuple(b.labels.shape) == (2, 5, 32, 48) and torch.all(b.labels[1, 3:] == -1)  # padded depth is "ignore"
-    assert b.min_slices == 3 and b.metadata["tomo_names"] == ["a.hdf", "b.hdf"]
+    assert b.min_slices == 3 and b.metadata.identifiers == (["Q109", "Q109"], ["a.hdf", "b.hdf"]) and b.metadata.split_id is None
 
 
 def test_cryovit_state_dict_is_reference_compatible():
@@ -284,3 +284,107 @@ def test_select_device_follows_local_rank(monkeypatch):
 
     with pytest.raises(RuntimeError, match="only 1 device"):
         sharding.select_device("cuda:3")
+
+
+def _write_tomo(path, D=4, with_data=True, seed=0):
+    from cryovit_amd import io
+
+    rng = np.random.default_rng(seed)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    feats = rng.standard_normal((16, D, 2, 3)).astype(np.float16)
+    lab = rng.integers(-1, 2, size=(D, 32, 48)).astype(np.int8)
+    vol = rng.integers(0, 256, size=(D, 32, 48), dtype=np.uint8)
+    with io.FileWriter(path) as f:
+        if with_data:
+            f.create_dataset("data", vol, compression="gzip")
+        f.create_dataset("dino_features", feats)
+        f.create_dataset("labels/mito", lab, compression="gzip")
+        f.create_dataset("labels/granule", lab, compression="gzip")
+    return feats, lab, vol
+
+
+def test_tomo_dataset_and_datamodule_records(tmp_path):
+    """tomo_dataset.py:89-146 + single/multi_sample_datamodule.py: record selection, item contents (input as stored, uint8
+    raw input scaled and given a channel axis, aux keys that exist, split id), collate metadata, refusal of train=True."""
+    import csv
+
+    import pytest
+
+    from cryovit_amd.config import compose, instantiate
+    from cryovit_amd.datamodules import MultiSampleDataModule, SingleSampleDataModule
+    from cryovit_amd.datasets import TomoDataset, collate_fn
+
+    root = tmp_path / "tomograms"
+    truth = {}
+    rows = []
+    for s, n, split in (("Q109", "a.hdf", 0), ("Q109", "b.hdf", 1), ("Q18", "c.hdf", 1), ("Q18", "d.hdf", 0)):
+        truth[(s, n)] = _write_tomo(root / s / n, D=3 + len(rows), with_data=(n != "d.hdf"), seed=len(rows))
+        rows.append({"sample": s, "tomo_name": n, "split_id": split})
+    (tmp_path / "csv").mkdir()
+    with open(tmp_path / "csv" / "splits.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["sample", "tomo_name", "split_id"])
+        w.writeheader()
+        w.writerows(rows)
+    cfg = compose("eval_model", ["model=cryovit", "datamodule=single", "datamodule.sample=[Q109]", "datamodule.split_id=1", "label_key=mito",
+                                 "paths.model_dir=/m", f"paths.data_dir={tmp_path}", f"paths.exp_dir={tmp_path}"])
+    dataset_fn = instantiate(cfg.datamodule.dataset)
+    dm = instantiate({k: v for k, v in cfg.datamodule.items() if k not in ("dataset", "dataloader")})(
+        split_file=tmp_path / "csv" / "splits.csv", dataset_fn=dataset_fn, dataloader_fn=None)
+    assert isinstance(dm, SingleSampleDataModule)
+    assert [r["tomo_name"] for r in dm.test_df()] == ["b.hdf"] and [r["tomo_name"] for r in dm.train_df()] == ["a.hdf"]
+    assert [r["tomo_name"] for r in dm.predict_df()] == ["a.hdf", "b.hdf"] and "split_id" not in dm.predict_df()[0]
+    ds = dm.test_dataset()
+    assert isinstance(ds, TomoDataset) and len(ds) == 1 and ds.aux_keys == ["data"]
+    item = ds[0]
+    feats, lab, vol = truth[("Q109", "b.hdf")]
+    assert item.sample == "Q109" and item.tomo_name == "b.hdf" and item.split_id == 1
+    assert item.data.dtype == torch.float16 and np.array_equal(item.data.numpy(), feats)
+    assert item.label.dtype == torch.int8 and np.array_equal(item.label.numpy(), lab)
+    assert np.array_equal(item.aux_data["data"], vol)  # aux data as stored (uint8)
+    batch = collate_fn([item])
+    assert batch.metadata.identifiers == (["Q109"], ["b.hdf"]) and batch.metadata.split_id.tolist() == [1]
+    assert tuple(batch.tomo_batch.shape) == (1, 4, 16, 2, 3) and batch.labels.dtype == torch.float32 and batch.aux_data["data"][0] is item.aux_data["data"]
+    with pytest.raises(IndexError):
+        ds[1]
+    # test on another sample: the whole sample, no split ids; missing aux keys are skipped (d.hdf has no "data")
+    multi = MultiSampleDataModule(["Q109"], None, "split_id", test_sample=["Q18"], split_file=tmp_path / "csv" / "splits.csv",
+                                  dataset_fn=dataset_fn)
+    ds2 = multi.test_dataset()
+    assert [r["tomo_name"] for r in multi.test_df()] == ["c.hdf", "d.hdf"] and ds2[0].split_id is None
+    assert "data" in ds2[0].aux_data and ds2[1].aux_data == {}
+    assert multi.val_df() == multi.train_df()  # split_id None: validate on the train set
+    # raw input key: uint8 -> /255 float32 with a channel axis (l.118-121); other label key
+    raw = TomoDataset([("Q109", "a.hdf")], input_key="data", label_key="granule", data_root=root, aux_keys=["labels/mito", "nope"])[0]
+    assert raw.data.dtype == torch.float32 and tuple(raw.data.shape) == (1, 3, 32, 48)
+    assert np.array_equal(raw.data[0].numpy(), truth[("Q109", "a.hdf")][2].astype(np.float32) / 255.0)
+    assert list(raw.aux_data) == ["labels/mito"]
+    with pytest.raises(AssertionError, match="Label key 'cristae' not found"):
+        TomoDataset([("Q109", "a.hdf")], input_key="data", label_key="cristae", data_root=root)[0]
+    with pytest.raises(NotImplementedError):
+        TomoDataset([("Q109", "a.hdf")], input_key="data", label_key="mito", data_root=root, train=True)
+    with pytest.raises(ValueError, match="No testing data"):
+        SingleSampleDataModule(["Q53"], None, "split_id", split_file=tmp_path / "csv" / "splits.csv", dataset_fn=dataset_fn).test_dataset()
+
+
+def test_eval_config_validation_and_exp_dir(tmp_path):
+    """config.py:234-286 (missing keys / invalid samples -> exit 1) and run/eval_model.py:100-140 (experiment directory)."""
+    import pytest
+
+    from cryovit_amd.config import compose, validate_experiment_config
+    from cryovit_amd.run.eval_model import setup_exp_dir
+
+    with pytest.raises(SystemExit) as e:
+        validate_experiment_config(compose("eval_model", ["model=cryovit", "datamodule=single", "datamodule.sample=Q109"]))  # label_key, paths
+    assert e.value.code == 1
+    base = ["model=cryovit", "datamodule=multi", "label_key=mito", "paths.model_dir=/m", f"paths.data_dir={tmp_path}", f"paths.exp_dir={tmp_path}"]
+    with pytest.raises(SystemExit):
+        validate_experiment_config(compose("eval_model", base + ["datamodule.sample=[Q109,NotASample]"]))
+    cfg = compose("eval_model", base + ["datamodule.sample=[Q18,Q109]", "datamodule.split_id=3"])
+    validate_experiment_config(cfg)
+    assert cfg.name == "multi_any_cryovit_mito" and cfg.callbacks.csv_writer.results_dir == f"{tmp_path}/results/multi_any_cryovit_mito"
+    with pytest.raises(AssertionError, match="Run training first"):
+        setup_exp_dir(cfg)
+    d = tmp_path / "multi_any_cryovit_mito" / "Q109_Q18" / "split_3"
+    d.mkdir(parents=True)
+    cfg = setup_exp_dir(cfg)
+    assert cfg.paths.exp_dir == d and cfg.ckpt_path == d / "weights.pt"

@@ -268,3 +268,108 @@ def test_graph_replay_equals_eager_config1_size(gpu):
         assert torch.equal(dice, ref["dice_sums"]) and float(dice[1]) > 0
     with pytest.raises(ValueError):
         g.run(torch.zeros(D, H, W + 16, dtype=torch.uint8, device=gpu))
+
+
+def test_eval_model_entry_point_against_oracle(gpu, tmp_path):
+    """``python -m cryovit_amd.training.eval_model`` (reference: training/eval_model.py:16-44, run/eval_model.py:143-197)
+    starting from files on disk: ``weights.pt`` under the experiment directory, ``csv/splits.csv``, tomograms holding
+    ``dino_features`` + ``labels/mito`` + ``data``.  Checks the experiment-directory contract, that records go through
+    ``TomoDataset`` -> ``collate_fn`` -> ``CryoVIT.test_step``, the prediction files (TestPredictionWriter layout) and the
+    metrics CSV (CsvWriter) against the fp32 CPU oracle head on the same weights: Dice within 1e-3, F1 within 1e-3,
+    probabilities within sigmoid'(0) * 5e-2 of the oracle's."""
+    import csv
+
+    from cryovit_amd import io
+    from cryovit_amd.training import eval_model as entry
+    from oracle import dice as od
+    from oracle import head as oh
+
+    ref = oh.CryoVITHead()
+    oh.rescaled_init_(ref, seed=5)
+    data_dir, exp_dir = tmp_path / "data", tmp_path / "exp"
+    name = "single_any_cryovit_mito"
+    (exp_dir / name / "Q109" / "split_1").mkdir(parents=True)
+    torch.save(ref.state_dict(), exp_dir / name / "Q109" / "split_1" / "weights.pt")
+    (data_dir / "csv").mkdir(parents=True)
+    rng = np.random.default_rng(31)
+    rows, truth = [], {}
+    for i, (D, split) in enumerate(((6, 1), (9, 0), (7, 1))):
+        vol = rng.integers(0, 256, size=(D, 48, 32), dtype=np.uint8)
+        feats = rng.standard_normal((1536, D, 3, 2)).astype(np.float16)
+        lab = rng.integers(-1, 2, size=(D, 48, 32)).astype(np.int8)
+        p = data_dir / "tomograms" / "Q109" / f"t{i}.hdf"
+        p.parent.mkdir(parents=True, exist_ok=True)
+        with io.FileWriter(p) as f:
+            f.create_dataset("data", vol, compression="gzip")
+            f.create_dataset("dino_features", feats)
+            f.create_dataset("labels/mito", lab, compression="gzip")
+        rows.append({"sample": "Q109", "tomo_name": f"t{i}.hdf", "split_id": split})
+        truth[f"t{i}.hdf"] = (vol, feats, lab, split)
+    with open(data_dir / "csv" / "splits.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["sample", "tomo_name", "split_id"])
+        w.writeheader()
+        w.writerows(rows)
+    entry.main(["model=cryovit", "datamodule=single", "datamodule.sample=Q109", "datamodule.split_id=1", "label_key=mito",
+                f"paths.model_dir={tmp_path}", f"paths.data_dir={data_dir}", f"paths.exp_dir={exp_dir}",
+                f"paths.results_dir={tmp_path / 'results'}"])
+    # split_id=1, no test_sample -> the test records are the validation split: t0 and t2
+    got = list(csv.DictReader(open(tmp_path / "results" / "results" / name / "Q109_1.csv")))
+    assert [r["tomo_name"] for r in got] == ["t0.hdf", "t2.hdf"] and list(got[0]) == ["sample", "tomo_name", "dice_metric", "f1_metric", "split_id"]
+    for r in got:
+        vol, feats, lab, split = truth[r["tomo_name"]]
+        assert int(r["split_id"]) == split == 1
+        with torch.no_grad():
+            probs = torch.sigmoid(ref.forward_volume(torch.from_numpy(feats).float()[None])[0, 0])
+        labt = torch.from_numpy(lab).float()
+        want_dice = od.dice_metric(probs, labt)
+        m = labt > -1
+        ph, y = (probs[m] > 0.5).double(), labt[m].double()
+        tp, fp, fn = (y * ph).sum(), ((1 - y) * ph).sum(), (y * (1 - ph)).sum()
+        pr, rc = tp / (tp + fp + 1e-6), tp / (tp + fn + 1e-6)
+        want_f1 = float(2 * pr * rc / (pr + rc + 1e-6))
+        assert abs(float(r["dice_metric"]) - want_dice) <= 1e-3, (r, want_dice)
+        assert abs(float(r["f1_metric"]) - want_f1) <= 1e-3, (r, want_f1)
+        pred = tmp_path / "results" / "predictions" / name / "Q109" / r["tomo_name"]
+        assert sorted(io.list_keys(pred)) == ["data", "mito", "mito_preds"]
+        pp = io.read_dataset(pred, "mito_preds")
+        assert pp.dtype == np.float32 and pp.shape == lab.shape
+        assert np.abs(pp - probs.numpy()).max() <= 5e-2 / 4 + 1e-4
+        assert np.array_equal(io.read_dataset(pred, "mito"), lab.astype(np.float32))  # collated labels are float (utils.py:40)
+        assert np.array_equal(io.read_dataset(pred, "data"), vol)  # aux "data" as stored in the source file
+    assert not (tmp_path / "results" / "predictions" / name / "Q109" / "t1.hdf").exists()
+    # the experiment-directory contract: a missing directory is an (logged, swallowed) error, nothing is written
+    entry.main(["model=cryovit", "datamodule=single", "datamodule.sample=Q18", "label_key=mito", f"paths.model_dir={tmp_path}",
+                f"paths.data_dir={data_dir}", f"paths.exp_dir={exp_dir}", f"paths.results_dir={tmp_path / 'results2'}"])
+    assert not (tmp_path / "results2" / "results").exists()
+
+
+def test_checkpoint_file_loader_upstream_layout(gpu, tmp_path):
+    """The path real weights take (reference load site run/dino_features.py:25-28,336): a state_dict file
+    in the UPSTREAM key layout under ``<model_dir>/<name>4_pretrain.pth`` -> ``load_encoder(model_dir=...)`` (weights_only
+    load, key-by-key packing) -> features equal to those of an engine built from the in-memory dict, and within tolerance
+    of the CPU oracle on the same weights.  Extra keys the upstream file carries (``mask_token``) are accepted; a file
+    lacking a block tensor is refused with the key's name."""
+    from cryovit_amd.models import load_encoder
+    from cryovit_amd.models.encoder import CHECKPOINT_FILES
+    from oracle import dinov2 as o
+    from oracle import preprocess as opre
+
+    sd = o.init_state_dict(o.VITS14_REG, 71)
+    assert CHECKPOINT_FILES["dinov2_vits14_reg"] == "dinov2_vits14_reg4_pretrain.pth"
+    torch.save(sd, tmp_path / CHECKPOINT_FILES["dinov2_vits14_reg"])
+    enc = load_encoder("dinov2_vits14_reg", model_dir=tmp_path, device=gpu)
+    vol = np.random.default_rng(72).integers(0, 256, size=(2, 64, 96), dtype=np.uint8)
+    f16, _ = enc.features_from_raw(torch.from_numpy(vol), 2)
+    mem = load_encoder("dinov2_vits14_reg", checkpoint=tmp_path / CHECKPOINT_FILES["dinov2_vits14_reg"], device=gpu)
+    f16b, _ = mem.features_from_raw(torch.from_numpy(vol), 2)
+    assert torch.equal(f16, f16b)
+    ref = o.forward_features(o.VITS14_REG, sd, opre.dino_transform(opre.load_scale(vol)))["x_norm_patchtokens"]  # [2, 24, 384]
+    got = f16.float().cpu().permute(1, 2, 3, 0).reshape(2, -1, 384)
+    err = (got - ref).abs()
+    assert float(err.max()) <= 1e-1 and float(err.mean()) <= 1e-2, (float(err.max()), float(err.mean()))
+    broken = {k: v for k, v in sd.items() if k != "blocks.3.mlp.fc2.weight"}
+    torch.save(broken, tmp_path / "broken.pth")
+    with pytest.raises(KeyError, match="blocks.3.mlp.fc2.weight"):
+        load_encoder("dinov2_vits14_reg", checkpoint=tmp_path / "broken.pth", device=gpu)
+    with pytest.raises(FileNotFoundError):
+        load_encoder("dinov2_vits14_reg", model_dir=tmp_path / "nowhere", device=gpu)
