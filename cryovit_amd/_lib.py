@@ -93,6 +93,7 @@ SIGNATURES = {
     "cvx_device_arch": (c_int, [C.c_char_p, c_int]),
     "cvx_set_option": (c_int, [C.c_char_p, c_int]),
     "cvx_debug_read_gemm256": (c_int, [c_void_p]),
+    "cvx_debug_read_gemm256p": (c_int, [c_void_p]),
     "cvx_gemm_bf16": (c_int, [C.POINTER(GemmDesc), c_void_p]),
     "cvx_set_gemm_event_hook": (c_int, [c_int, c_void_p, c_void_p, c_int]),
     "cvx_get_gemm_event_count": (c_int, []),

@@ -1,6 +1,7 @@
 // Dense / implicit-GEMM launchers and fused epilogues (gfx950).  See gemm_core.h for the tile kernel.
 #include "gemm_core.h"
 #include "gemm256.h"
+#include "gemm256p.h"
 #include "gemm4w.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
@@ -315,8 +316,17 @@ __global__ __launch_bounds__(G256_THREADS) void k_gemm256_mreg(const uint16_t* A
     gemm256_body<VARIANT>(A, lda, Wt, ldw, nk, (long)tr * 256, (long)tl * 256, epi, smem);
 }
 
+// persistent form (gemm256p.h): one workgroup per CU walks its tiles, the operand stream runs across tile boundaries
+template <class Epi, bool FULL, bool DBG = false>
+__global__ __launch_bounds__(G256_THREADS) void k_gemm256p_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
+                                                                 int tiles_n, int tiles_m, int group_l, int xcd_stagger, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256p_body<Epi, FULL, DBG>(Wt, ldw, A, lda, nk, tiles_n, tiles_m, group_l, xcd_stagger, epi, smem);
+}
+
 // tuning switches (cvx_set_option): A/B the tile kernels and pipeline schedules inside ONE process
-static std::atomic<int> g_use_gemm256{1}, g_gemm256_variant{5}, g_gemm_stagger{0};  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
+static std::atomic<int> g_tile_group_l_host{8};  // host copy of g_tile_group_l (the persistent kernel takes it as an argument)
+static std::atomic<int> g_use_gemm256{1}, g_gemm256_variant{9}, g_gemm_stagger{0};  // 9 = persistent (gemm256p.h)  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
 template <class Epi> static constexpr int epilogue_cycles() { return 12000; }       // bf16 store epilogues (stamped)
 template <> constexpr int epilogue_cycles<EpiResid>() { return 40000; }              // fp32 read-modify-write
 template <> constexpr int epilogue_cycles<EpiF32>() { return 20000; }
@@ -351,6 +361,29 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
         return cvx_check_launch();
     }
     const int variant = g_gemm256_variant;
+    if constexpr (!MREG && (epi_has_preload<Epi>::value || epi_has_produce<Epi>::value)) {
+        if (variant == 9 || variant == 29) {
+            // one workgroup per CU (128 KiB of LDS each), a multiple of 8 so every XCD gets the same number
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0, n = 0;
+                CVX_HIP(hipGetDevice(&dev));
+                CVX_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+                n_cu = n >= 8 ? n / 8 * 8 : 8;
+            }
+            const int ntiles = tiles_n * tiles_m;
+            const int grid = ntiles >= n_cu ? n_cu : (ntiles + 7) / 8 * 8;
+            const bool full = M % 256 == 0 && epi.n_valid == Npad;
+            auto kp = full ? k_gemm256p_nreg<Epi, true> : k_gemm256p_nreg<Epi, false>;
+#ifdef CVX_ABLATION
+            if (variant == 29) kp = k_gemm256p_nreg<Epi, true, true>;  // stamped (interior tiles only)
+#endif
+            CVX_HIP(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS_BYTES));
+            hipLaunchKernelGGL(kp, dim3(grid), dim3(G256_THREADS), G256P_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / BK), tiles_n, tiles_m,
+                               (int)g_tile_group_l_host, ntiles > grid ? (int)g_gemm_stagger : 0, epi);
+            return cvx_check_launch();
+        }
+    }
     void (*k)(const uint16_t*, long, const uint16_t*, long, int, int, int, Epi, int);
     if constexpr (MREG) {
         k = k_gemm256_mreg<Epi, 0>;
@@ -457,6 +490,10 @@ extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
     CVX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvx::g_gemm256_dbg), sizeof(unsigned long long) * 32));
     return 0;
 }
+extern "C" int cvx_debug_read_gemm256p(unsigned long long* out96) {
+    CVX_HIP(hipMemcpyFromSymbol(out96, HIP_SYMBOL(cvx::g_gemm256p_dbg), sizeof(unsigned long long) * 96));
+    return 0;
+}
 
 static std::atomic<int> g_conv_halo{1};  // cvx_set_option("conv_halo", 0) forces the implicit-GEMM kernel (A/B runs, tests)
 
@@ -474,10 +511,13 @@ extern "C" int cvx_set_option(const char* name, int value) {
         if (!one_of({0, 1, 2})) return cvx_fail("set_option: use_gemm256 must be 0, 1 or 2");
         g_use_gemm256 = value;
     } else if (!strcmp(name, "gemm256_variant")) {
-        if (!one_of({0, 1, 2, 5, 6, 7, 8}) && !(abl && one_of({10, 11, 12, 13, 20, 21})))
+        if (!one_of({0, 1, 2, 5, 6, 7, 8, 9}) && !(abl && one_of({10, 11, 12, 13, 20, 21, 29})))
             return cvx_fail("set_option: unknown gemm256_variant (ablation variants need a -DCVX_ABLATION build)");
         g_gemm256_variant = value;
-    } else if (!strcmp(name, "gemm_stagger")) g_gemm_stagger = value != 0;
+    } else if (!strcmp(name, "gemm_stagger")) {
+        if (value < 0 || value > 1000000) return cvx_fail("set_option: gemm_stagger is a cycle count in [0, 1e6]");
+        g_gemm_stagger = value;  // persistent kernel: start offset between XCDs, cycles; the one-shot kernels: on / off
+    }
     else if (!strcmp(name, "gemm_tail_split")) g_tail_split = value != 0;
     else if (!strcmp(name, "conv_halo")) g_conv_halo = value != 0;
     else if (!strcmp(name, "attn_variant")) {
@@ -487,6 +527,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
     } else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value != 0;
     else if (!strcmp(name, "tile_group_l")) {
         if (value < 1) return cvx_fail("set_option: tile_group_l must be >= 1");
+        g_tile_group_l_host = value;
         CVX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cvx::g_tile_group_l), &value, sizeof(int)));
     }
     else return cvx_fail("set_option: unknown option");

@@ -1,0 +1,394 @@
+// Persistent form of the 256x256x64 phase-pipelined bf16 GEMM tile (gemm256.h, schedule "variant 5").
+//
+// One workgroup per CU walks a static list of output tiles; the LDS-DMA operand stream NEVER stops at a tile boundary:
+//
+//   * while a tile's last five MFMA phases run, the DMA pieces they issue already belong to the NEXT tile's first K tiles
+//     (a workgroup's last tile re-fetches its own first K tile: harmless reads, drained before exit), so no tile but the
+//     first pays the ~3.2 k-cycle pipeline fill and no K tile runs on the drained `vmcnt(0)` schedule;
+//   * the epilogue (convert / gate / residual update, staged through LDS into whole-row stores) runs with five half-tiles
+//     of the next tile in flight.  Its staging buffers are the three ring slots of the finished tile that no DMA targets
+//     until the next tile's first phase (L-lo, R-hi, L-hi of the last K tile: 48 KiB, 6 KiB per wave);
+//   * `vmcnt` retires loads, stores and LDS-DMA together IN ISSUE ORDER, so the S stores a wave issues in the epilogue (and
+//     the one constants piece, below) sit between half-tile 4 and half-tile 5 of the next tile in its queue: the first three
+//     counted waits of that tile's first K tile are 4+S / 5+S / 7+S instead of 4 / 4 / 6.  S is exact only when every store executes, i.e. for
+//     launches whose tiles are all interior (FULL: M % 256 == 0, no padded output columns): there the stores are
+//     unpredicated.  Other launches keep predicated stores and the conservative 4 / 4 / 6 (correct, they only over-wait).
+//
+// Barrier structure per tile (I = all 8 waves, G0 / G1 = waves 0-3 / 4-7, G1 runs one barrier behind inside the K loop):
+//   [G1: I] K loop ... [G0: I]  epilogue  I  -> next tile
+// The barrier after the epilogue orders every wave's staging reads before the first DMA into those slots (issued in the
+// first MFMA segment of the next tile).
+#pragma once
+#include "gemm256.h"
+
+namespace cvx {
+
+constexpr int G256P_LDS_BYTES = G256_LDS_BYTES + 8 * 1024;  // ring + one 1-KiB constants piece per wave
+
+// vector-memory operations ONE wave issues in the staged epilogue of one interior tile and that may still be in flight
+// when the next tile starts (the residual epilogue's loads are consumed, hence complete, before its last stores)
+template <class Epi> constexpr int epi_stores_per_wave() {
+    if constexpr (epi_has_preload<Epi>::value) return 32;                        // 4 x 8 float4 stores
+    else return 4 * (32 / (64 / (4 * Epi::OUT16 * 2 / 16)));                      // 4 x (32 rows / rows per instruction)
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// position `id` of the XCD-grouped tile sequence -> tile coordinates (the mapping of tile_coords() in gemm_core.h)
+__device__ __forceinline__ void tile_from_seq(int id, int tiles_r, int tiles_l, int GROUP_L, int& tr, int& tl) {
+    const int per_band = GROUP_L * tiles_r;
+    const int band = id / per_band, in = id - band * per_band;
+    const int l_first = band * GROUP_L;
+    const int gl = min(GROUP_L, tiles_l - l_first);
+    tl = l_first + in % gl;
+    tr = in / gl;
+}
+
+// diagnostic build only (DBG, -DCVX_ABLATION): cycle stamps of one workgroup's first 8 tiles, waves 0 and 4:
+// [wave>>2][tile][0..5] = K loop start, K loop end, epilogue start (after the un-stagger barrier), epilogue end, after the
+// post-epilogue barriers, end of the tile's first K tile
+__device__ unsigned long long g_gemm256p_dbg[2 * 8 * 6];
+
+template <class Epi, bool FULL, bool DBG = false>
+__device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat, long ldr, const uint16_t* __restrict__ Lmat, long ldl,
+                                              int nk, int tiles_r, int tiles_l, int group_l, int xcd_stagger, const Epi& epi, char* smem) {
+    static_assert(epi_has_preload<Epi>::value || epi_has_produce<Epi>::value, "persistent tile: LDS-staged epilogues only");
+    constexpr bool F16 = epi_is_f16<Epi>::value;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3, wl = wave >> 2;
+    const int total = 4 * nk;
+
+    // ---- this workgroup's tiles: XCD x = blockIdx & 7 owns a contiguous chunk of the sequence (its L2 sees neighbouring
+    //      tiles); the 32 workgroups of an XCD take 32 consecutive positions per round ----
+    const int ntiles = tiles_r * tiles_l;
+    const int xcd = blockIdx.x & 7, lslot = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int q8 = ntiles >> 3, rem = ntiles & 7;
+    const int c0 = xcd < rem ? xcd * (q8 + 1) : rem * (q8 + 1) + (xcd - rem) * q8;
+    const int cnt = q8 + (xcd < rem ? 1 : 0);
+    int id = lslot;
+    if (id >= cnt) return;  // (uniform for the workgroup; no barrier has been executed)
+    // De-phase the XCDs once: tiles take the same time everywhere, so without this all 256 workgroups reach their epilogue
+    // together for the whole launch and every tile boundary is a chip-wide store burst (tens of MB) that the in-order vmcnt
+    // queue then has to see retired a few phases into the next tile.  The 32 workgroups of ONE XCD stay in step (they
+    // stream the same operand panels through their L2); XCD x starts x * xcd_stagger cycles late and keeps that offset.
+    if (xcd_stagger > 0 && xcd > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long want = (unsigned long long)xcd * (unsigned)xcd_stagger;
+        while (__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(32);
+    }
+
+    uint32_t offR[2][2], offL[2][2];  // [half][piece] LDS-DMA source offsets, BYTES relative to the tile origin
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = j * G256_THREADS + tid;
+        const int hr = c >> 3, ch = ((c & 7) ^ swz_chunk(hr)) << 3;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int tr_ = (hr >> 5) * 64 + half * 32 + (hr & 31);
+            offR[half][j] = (uint32_t)(sigma_row<4>(tr_) * ldr + ch) * 2u;
+            const int tl_ = (hr >> 6) * 128 + half * 64 + (hr & 63);
+            offL[half][j] = (uint32_t)(tl_ * ldl + ch) * 2u;
+        }
+    }
+    long r0, l0;
+    const uint16_t *Rc, *Lc, *Rn, *Ln;  // operand panels of the current / next tile
+    auto panels = [&](int pos, const uint16_t*& Rp, const uint16_t*& Lp, long& rr, long& ll) {
+        int tr, tl;
+        tile_from_seq(c0 + pos, tiles_r, tiles_l, group_l, tr, tl);
+        rr = (long)tr * 256; ll = (long)tl * 256;
+        Rp = Rmat + rr * ldr; Lp = Lmat + ll * ldl;
+    };
+    panels(id, Rc, Lc, r0, l0);
+    long rn = r0, ln = l0;
+    Rn = Rc; Ln = Lc;
+    if (id + per < cnt) panels(id + per, Rn, Ln, rn, ln);
+
+    // Per-column constants of the epilogue (bias, LayerScale gamma) reach the wave through one LDS-DMA piece per tile, issued
+    // in the tile's FIRST K tile into a 1-KiB slot behind the ring: a register load in the epilogue would be the YOUNGEST entry
+    // of the in-order vmcnt queue, and waiting for it would drain the five half-tiles in flight for the next tile.
+    // Piece layout: lanes 0-15 bias[nw + 4 l ..], lanes 16-31 gamma[..] (bias again when the epilogue has no gamma), 32-63 unused.
+    char* cbuf = smem + G256_LDS_BYTES + wave * 1024;
+    auto issue_consts = [&](long rr) {
+        int l2 = tid & 63;
+        asm volatile("" : "+v"(l2));
+        const float* src = epi.bias;
+        if constexpr (epi_has_preload<Epi>::value) src = (l2 & 16) ? epi.gamma : epi.bias;
+        glds16(src + rr + wr * 64 + 4 * (l2 & 15), cbuf);
+    };
+
+    int slot0 = 0;  // ring slot of the current tile's half-tile 0 (0 or 4)
+    // One LDS-DMA half-tile = two 1-KiB pieces per wave.  The source is a wave-uniform byte pointer (SGPR pair) + a 32-bit
+    // per-lane byte offset, the form hipcc lowers to `global_load_lds_dwordx4 voff, s[base]` without any per-piece VALU work;
+    // `slot` is the ring slot counted from the K tile's own group (values 5..8 = the next K tile's L-lo, R-hi, L-hi and the
+    // R-lo after that).  Everything that could be selected at run time per piece (which tile, which K tile) is decided by the
+    // CALLER once per K tile: scalar work in the MFMA segments is on the loop's critical path (measured: 25 extra SALU
+    // instructions per K tile cost 135 of 2810 cycles).
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(CVX_LDS_AS char*)smem + wave * 1024;  // LDS byte address of this wave's piece in slot 0
+    auto dma = [&](const char* src, const uint32_t (&off)[2], const char* st, int slot) {
+        const uint32_t dst = lds0 + (((uint32_t)(st - smem) + slot * G256_HALF_BYTES) & (G256_LDS_BYTES - 1));
+        // saddr form (SGPR base + 32-bit lane offset): no address VALU at all; M0 (the LDS destination) is written in the same
+        // statement that uses it (hipcc does not preserve it across statements); one wait state between an SALU write of M0
+        // and the LDS-DMA that reads it
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+                     "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "v"(off[0]), "v"(off[1]), "s"(src), "s"(dst) : "memory");
+    };
+    const int sw = (lane & 15) >> 1;
+    const int fo = (lane & 15) * 128 + (((lane >> 4) ^ sw) << 4);
+    const int foR = wr * 32 * 128 + fo, foL = wl * 64 * 128 + fo;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 rlo[2][2], rhi[2][2], lf[4][2];
+
+    auto read_r = [&](bf16x8 (&dst)[2][2], const char* half) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) dst[f][ks] = *(const bf16x8*)(half + ((foR + f * 2048) ^ (ks << 6)));
+    };
+    auto read_l = [&](const char* half) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) lf[f][ks] = *(const bf16x8*)(half + ((foL + f * 2048) ^ (ks << 6)));
+    };
+    // ZERO: first K tile of a tile after the first -- the k-step-0 MFMAs start from C = 0 (no accumulator clearing pass)
+    auto mma = [&](const bf16x8 (&r)[2][2], int a0, int b0, auto zero_tag) {
+        constexpr bool ZERO = decltype(zero_tag)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    acc[a0 + a][b0 + b] = mfma16x16x32<F16>(r[a][ks], lf[b][ks], (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[a0 + a][b0 + b]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    constexpr int S = FULL ? epi_stores_per_wave<Epi>() : 0;
+    // One K tile.  Rk1 / Lk1: operand streams at the NEXT K tile (the next tile's K tile 0 after this tile's last one),
+    // Rk2: the R stream one K tile further -- wave-uniform byte pointers chosen by the caller.
+    auto ktile = [&](const char* st, const char* Rk1, const char* Lk1, const char* Rk2, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int E = FIRST ? S : 0;
+        read_r(rlo, st);                                  // ---- phase 0: (R-lo, L-lo) ----
+        read_l(st + G256_HALF_BYTES);
+        wait_vmcnt<4 + E>();
+        __builtin_amdgcn_s_barrier();
+        if constexpr (FIRST) issue_consts(r0);            // (one more entry between the epilogue's stores and half-tile 5)
+        dma(Lk1, offL[0], st, 5);
+        mma(rlo, 0, 0, first_tag);
+        __builtin_amdgcn_s_barrier();
+        read_r(rhi, st + 2 * G256_HALF_BYTES);            // ---- phase 1: (R-hi, L-lo) ----
+        wait_vmcnt<4 + E + (FIRST ? 1 : 0)>();
+        __builtin_amdgcn_s_barrier();
+        dma(Rk1, offR[1], st, 6);
+        mma(rhi, 2, 0, first_tag);
+        __builtin_amdgcn_s_barrier();
+        read_l(st + 3 * G256_HALF_BYTES);                 // ---- phase 2: (R-hi, L-hi) ----
+        wait_vmcnt<6 + E + (FIRST ? 1 : 0)>();
+        __builtin_amdgcn_s_barrier();
+        dma(Lk1, offL[1], st, 7);
+        mma(rhi, 2, 4, first_tag);
+        __builtin_amdgcn_s_barrier();
+        wait_vmcnt<4>();                                  // ---- phase 3: (R-lo, L-hi) ---- (retires the epilogue's stores too)
+        __builtin_amdgcn_s_barrier();
+        dma(Rk2, offR[0], st, 8);
+        mma(rlo, 0, 4, first_tag);
+        __builtin_amdgcn_s_barrier();
+    };
+    // all K tiles of the current tile after the first: the plain ones, then the last two, whose look-ahead crosses into the
+    // next tile (peeled so that the loop body carries no per-tile selection at all)
+    constexpr long KB = BK * 2;  // bytes per K tile along a row
+    auto ktiles_1_to_end = [&]() {
+        const char* rc = (const char*)Rc;
+        const char* lc = (const char*)Lc;
+        const char* rn = (const char*)Rn;
+        const char* lnx = (const char*)Ln;
+        int par = slot0 >> 2;
+        for (int t = 1; t < nk - 2; ++t) {
+            par ^= 1;
+            ktile(smem + par * 4 * G256_HALF_BYTES, rc + (t + 1) * KB, lc + (t + 1) * KB, rc + (t + 2) * KB, std::false_type{});
+        }
+        par ^= 1;  // t = nk - 2: R-lo two K tiles ahead is the next tile's first
+        ktile(smem + par * 4 * G256_HALF_BYTES, rc + (long)(nk - 1) * KB, lc + (long)(nk - 1) * KB, rn, std::false_type{});
+        par ^= 1;  // t = nk - 1: the whole look-ahead belongs to the next tile
+        ktile(smem + par * 4 * G256_HALF_BYTES, rn, lnx, rn + KB, std::false_type{});
+    };
+
+    // ---- epilogue of the finished tile at (r0, l0); staging = ring slots 1..3 of the last K tile's group ----
+    auto epilogue = [&]() {
+        // every per-lane quantity of the epilogue is re-derived from this opaque copy of the lane id: otherwise hipcc hoists
+        // them (store addresses, staging offsets: ~40 VGPRs) out of the tile loop and keeps them live across the K loop,
+        // which already runs at the 256-register limit of a 512-thread workgroup
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        char* stg_base = smem + (((slot0 >> 2) + nk - 1) & 1) * 4 * G256_HALF_BYTES + G256_HALF_BYTES + wave * 6144;
+        const int gq = lane >> 4;
+        typename Epi::template Ctx<16> ctx;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float4 t = *(const float4*)(cbuf + (gq * 16 + 4 * f) * 4);
+            ctx.bias[f * 4 + 0] = t.x; ctx.bias[f * 4 + 1] = t.y; ctx.bias[f * 4 + 2] = t.z; ctx.bias[f * 4 + 3] = t.w;
+            if constexpr (epi_has_preload<Epi>::value) {
+                const float4 u = *(const float4*)(cbuf + 256 + (gq * 16 + 4 * f) * 4);
+                ctx.gamma[f * 4 + 0] = u.x; ctx.gamma[f * 4 + 1] = u.y; ctx.gamma[f * 4 + 2] = u.z; ctx.gamma[f * 4 + 3] = u.w;
+            }
+        }
+        if constexpr (epi_has_preload<Epi>::value) {
+            // fp32 residual update x += gamma * (acc + bias): 16 rows x 64 columns of the wave's tile at a time are transposed
+            // through LDS so one instruction covers 4 rows x 256 contiguous bytes; the x values of the NEXT 32 rows are
+            // requested before the current ones are consumed (two register sets) -- the round trip to HBM, not the
+            // arithmetic, is what this epilogue waits for.  Addresses are a wave-uniform base (SGPRs) + 8 loop-invariant
+            // 32-bit lane offsets: per-access 64-bit address pairs would not fit beside 128 accumulators + 64 x registers.
+            constexpr int PITCH = 68;
+            float* stg = (float*)stg_base;
+            const int mrow = lane >> 4, ncol = (lane & 15) * 4;
+            const uint32_t ldx = (uint32_t)epi.ldx;
+            const long mw = l0 + wl * 128, nw = r0 + wr * 64;      // first row / column of this wave's 128 x 64 part
+            float* xw = epi.x + mw * epi.ldx + nw;                 // wave-uniform
+            const long mleft = epi.m_valid - mw;                   // rows / columns of the part inside the problem
+            const bool nok = FULL || nw + ncol < epi.n_valid;
+            uint32_t loff[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) loff[i] = ((uint32_t)(mrow + 4 * i) * ldx + (uint32_t)ncol) * 4u;  // BYTES (saddr + voffset form)
+            // units of 16 rows (one accumulator column block b): the x values of unit u + 2 are requested before unit u is consumed
+            float4 xv[3][4];
+            auto request = [&](float4 (&dst)[4], int u) {
+                const char* xu = (const char*)(xw + (long)(16 * u) * ldx);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    dst[i] = (Epi::ACCUM && (FULL || (16 * u + 4 * i + mrow < mleft && nok))) ? ld_stream((const float*)(xu + loff[i])) : float4{0.f, 0.f, 0.f, 0.f};
+            };
+            request(xv[0], 0);
+            request(xv[1], 1);
+            // gamma * (acc + bias) in place, so the 32 bias / gamma registers are dead before the third x set is requested
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[f][b][e] = ctx.gamma[f * 4 + e] * (acc[f][b][e] + ctx.bias[f * 4 + e]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u + 2 < 8) request(xv[(u + 2) % 3], u + 2);
+                __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists all the requests to the top and spills)
+                char* xu = (char*)(xw + (long)(16 * u) * ldx);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const f32x4 a = acc[f][u];
+                    *(float4*)(stg + (lane & 15) * PITCH + 16 * gq + 4 * f) = float4{a[0], a[1], a[2], a[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 d = *(const float4*)(stg + (4 * i + mrow) * PITCH + ncol);
+                    const float4 xq4 = xv[u % 3][i];
+                    if (FULL || (16 * u + 4 * i + mrow < mleft && nok)) {
+                        float4 o;
+                        o.x = xq4.x + d.x; o.y = xq4.y + d.y; o.z = xq4.z + d.z; o.w = xq4.w + d.w;
+                        st_stream((float*)(xu + loff[i]), o);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            constexpr int O16 = Epi::OUT16, ROWB = 4 * O16 * 2, PITCHB = ROWB + 16, LPR = ROWB / 16, RPI = 64 / LPR;
+            static_assert(32 * PITCHB <= 6144, "staging buffer of a wave");
+            char* stg = stg_base;
+            const int srow = lane / LPR, spiece = lane % LPR;
+            const uint32_t ldc = (uint32_t)epi.ldc;
+            const long mw = l0 + wl * 128, ow = (r0 + wr * 64) >> Epi::OUT_SHIFT;   // first row / output column of this wave's part
+            uint16_t* outw = epi.out + mw * epi.ldc + ow;                           // wave-uniform
+            const long mleft = epi.m_valid - mw;
+            const bool ook = FULL || ow + spiece * 8 < (epi.n_valid >> Epi::OUT_SHIFT);
+            uint32_t loff[32 / RPI];
+#pragma unroll
+            for (int i = 0; i < 32 / RPI; ++i) loff[i] = ((uint32_t)(RPI * i + srow) * ldc + (uint32_t)(spiece * 8)) * 2u;  // BYTES
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                char* oq = (char*)(outw + (long)(32 * q) * ldc);
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    float v[16];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][2 * q + bb][e];
+                    uint32_t w[O16 / 2];
+                    epi.produce(ctx, v, w);
+                    char* dst = stg + (16 * bb + (lane & 15)) * PITCHB + gq * (O16 * 2);
+                    if constexpr (O16 == 16) {
+                        *(uint4*)dst = uint4{w[0], w[1], w[2], w[3]};
+                        *(uint4*)(dst + 16) = uint4{w[4], w[5], w[6], w[7]};
+                    } else {
+                        *(uint4*)dst = uint4{w[0], w[1], w[2], w[3]};
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i) {
+                    const int row = RPI * i + srow;
+                    const uint4 d = *(const uint4*)(stg + row * PITCHB + spiece * 16);
+                    if (FULL || (32 * q + row < mleft && ook)) {
+                        if constexpr (O16 == 16) st_stream((uint16_t*)(oq + loff[i]), d);
+                        else *(uint4*)(oq + loff[i]) = d;  // 64-B segments: left to the L2's write combining
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- pipeline fill (first tile only): half-tiles 0..4 = K tile 0 and R-lo of K tile 1 ----
+    issue_consts(r0);
+    dma((const char*)Rc, offR[0], smem, 0);
+    dma((const char*)Lc, offL[0], smem, 1);
+    dma((const char*)Rc, offR[1], smem, 2);
+    dma((const char*)Lc, offL[1], smem, 3);
+    dma((const char*)Rc + KB, offR[0], smem, 4);
+    wait_vmcnt<6>();
+    __builtin_amdgcn_s_barrier();
+    if (wl == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 run one barrier behind
+    [[maybe_unused]] int dbg_tile = 0;
+    const bool dbg_on = DBG && blockIdx.x == 8 * 10 && (wave & 3) == 0 && (tid & 63) == 0;
+    auto dbg = [&](int k) {
+        if constexpr (DBG) {
+            const unsigned long long t = stamp();
+            if (dbg_on && dbg_tile < 8) g_gemm256p_dbg[((wave >> 2) * 8 + dbg_tile) * 6 + k] = t;
+        }
+    };
+    dbg(0);
+    ktile(smem, (const char*)Rc + KB, (const char*)Lc + KB, (const char*)Rc + 2 * KB, std::false_type{});
+    dbg(5);
+    for (;;) {
+        ktiles_1_to_end();
+        dbg(1);
+        if (wl == 0) __builtin_amdgcn_s_barrier();  // pairs with the stagger barrier: both groups are in step again
+        dbg(2);
+        epilogue();
+        dbg(3);
+        id += per;
+        if (id >= cnt) break;
+        slot0 = (slot0 + total) & 7;
+        Rc = Rn; Lc = Ln; r0 = rn; l0 = ln;
+        if (id + per < cnt) panels(id + per, Rn, Ln, rn, ln);  // (else: the last tile prefetches itself)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // every wave is done with its staging slots
+        if (wl == 1) __builtin_amdgcn_s_barrier();  // stagger again
+        dbg(4);
+        if constexpr (DBG) ++dbg_tile;
+        dbg(0);
+        ktile(smem + (slot0 >> 2) * 4 * G256_HALF_BYTES, (const char*)Rc + KB, (const char*)Lc + KB, (const char*)Rc + 2 * KB, std::true_type{});
+        dbg(5);
+    }
+    wait_vmcnt<0>();  // the last tile's look-ahead DMA must have landed before the workgroup releases its LDS
+}
+
+}  // namespace cvx

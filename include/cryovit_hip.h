@@ -45,6 +45,9 @@ int cvx_device_arch(char* buf, int buflen);
 int cvx_set_option(const char* name, int value);
 /* diagnostic: per-wave cycle sums {load, load-barrier, mma, mma-barrier} x 8 waves written by gemm256 variant 20 */
 int cvx_debug_read_gemm256(unsigned long long* out32);
+/* diagnostic: cycle stamps of the persistent tile kernel (variant 29, -DCVX_ABLATION builds only; zeros otherwise):
+ * [wave group 2][tile 8][6] = K-loop start, K-loop end, epilogue start, epilogue end, next tile released, first K tile done */
+int cvx_debug_read_gemm256p(unsigned long long* out96);
 
 /* ---------------------------------------------------------------------------------------------------
  * Dense GEMM  C[M,N] = A[M,K] * W[N,K]^T, bf16 operands (K contiguous, leading dims in elements),

@@ -476,11 +476,12 @@ def gemm256_variant(request):
     _lib.set_option("gemm256_variant", DEFAULT_GEMM[1])
 
 
-DEFAULT_GEMM = (1, 5)  # (tile kernel: 1 = 8-wave gemm256.h, 2 = 4-wave gemm4w.h; gemm256 schedule variant)
+DEFAULT_GEMM = (1, 9)  # (tile kernel: 1 = 8-wave gemm256.h, 2 = 4-wave gemm4w.h; schedule variant, 9 = persistent gemm256p.h)
 
 
-@pytest.mark.parametrize("gemm256_variant", [(1, 0), (1, 1), (1, 5), (1, 6), (2, 0)], indirect=True)
-@pytest.mark.parametrize("M,N,K", [(1029 * 2 + 7, 512, 256), (3000, 256, 1536), (2048, 1536, 4096), (66500, 512, 256)])
+@pytest.mark.parametrize("gemm256_variant", [(1, 0), (1, 1), (1, 5), (1, 6), (1, 9), (2, 0)], indirect=True)
+@pytest.mark.parametrize("M,N,K", [(1029 * 2 + 7, 512, 256), (3000, 256, 1536), (2048, 1536, 4096), (66500, 512, 256),
+                                   (17920, 1536, 1536), (18000, 1536, 320)])
 def test_gemm256_bf16_and_resid(gpu, M, N, K, gemm256_variant):
     from cryovit_amd._lib import EPI_BF16, EPI_RESID
     from cryovit_amd.engine import ops
@@ -499,6 +500,8 @@ def test_gemm256_bf16_and_resid(gpu, M, N, K, gemm256_variant):
     ops.gemm(EPI_RESID, A, Wd, x, b.to(gpu), m=M, n=N, gamma=gm.to(gpu))
     assert torch.allclose(x[:M].cpu(), x0 + gm * ref, atol=2e-4, rtol=1e-4)
     # (M = 66500: 260 x 2 = 520 tiles -> the launch is cut into 2 whole rounds of 256x256 tiles + a 128x128-tile tail)
+    # (M = 17920 = 70 x 256, N = 1536: 420 interior tiles -> the persistent kernel's workgroups walk 1-2 tiles each with exact
+    #  store counts in the waits; M = 18000: the same walk with predicated stores and the conservative waits, odd K-tile count)
     # race screen: the pipeline's waits/barriers are hand-counted -- repeated launches must be bit-identical
     outs = []
     for _ in range(8 if M < 10000 else 2):
@@ -509,7 +512,7 @@ def test_gemm256_bf16_and_resid(gpu, M, N, K, gemm256_variant):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
-@pytest.mark.parametrize("gemm256_variant", [(1, 5), (2, 0)], indirect=True)
+@pytest.mark.parametrize("gemm256_variant", [(1, 5), (1, 9), (2, 0)], indirect=True)
 def test_gemm256_swiglu_vt_patch(gpu, gemm256_variant):
     from cryovit_amd._lib import EPI_PATCH, EPI_SWIGLU, EPI_VT
     from cryovit_amd.engine import ops
@@ -525,6 +528,17 @@ def test_gemm256_swiglu_vt_patch(gpu, gemm256_variant):
     h = bf(a).float() @ bf(w12).float().T + b12
     ref = F.silu(h[:, :Hd]) * h[:, Hd:]
     assert torch.allclose(out[:M].float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    # SwiGLU over 40 x 8 = 320 interior tiles (persistent kernel: several tiles per workgroup, unpredicated stores)
+    M2, N2 = 10240, 2048
+    a2 = rnd(M2, K, seed=76)
+    w2, b2 = rnd(N2, K, seed=77, scale=K**-0.5), rnd(N2, seed=78)
+    iw2 = torch.stack([w2[: N2 // 2].reshape(-1, 8, K), w2[N2 // 2 :].reshape(-1, 8, K)], 1).reshape(N2, K)
+    ib2 = torch.stack([b2[: N2 // 2].reshape(-1, 8), b2[N2 // 2 :].reshape(-1, 8)], 1).reshape(N2)
+    out2 = torch.zeros(ops.alloc_rows(M2), N2 // 2, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_SWIGLU, padded_bf16(a2, ops.alloc_rows(M2), K, gpu), bf(iw2).to(gpu), out2, ib2.to(gpu), m=M2, n=N2)
+    h2 = bf(a2).float() @ bf(w2).float().T + b2
+    assert torch.allclose(out2[:M2].float().cpu(), F.silu(h2[:, : N2 // 2]) * h2[:, N2 // 2 :], atol=2e-2, rtol=1e-2)
+    assert torch.all(out2[M2:] == 0)
     # V^T (MREG orientation): 4 heads -> N = 256
     b_, heads, nt = 5, 4, 261
     ntp, kp, C = ops.round_up(nt, 8), 320, heads * 64

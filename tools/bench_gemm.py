@@ -43,7 +43,12 @@ for name, (epi, K, N) in shapes.items():
     else:
         out = torch.zeros(ops.alloc_rows(M), N, dtype=torch.bfloat16, device=dev)
     bufs[name] = (a, w, bias, out, torch.ones(N, device=dev) * 1e-3)
-variants = [int(v) for v in args.variants.split(",")]
+def parse_variant(tok):  # "9s4000" = variant 9 with gemm_stagger 4000 (cycles between XCD start offsets)
+    v, _, st = tok.partition("s")
+    return (int(v), int(st) if st else 0)
+
+
+variants = [parse_variant(v) for v in args.variants.split(",")]
 groups = [int(v) for v in args.group_l.split(",")] if args.group_l else []
 if groups:
     base_variant = variants[0]
@@ -57,6 +62,8 @@ def run(name, v, reps=4):
     if groups:
         _lib.set_option("tile_group_l", v)
         v = base_variant
+    v, stag = v
+    _lib.set_option("gemm_stagger", stag)
     _lib.set_option("gemm_tail_split", 0 if 1000 <= v < 2000 else 1)  # 1000 + v = schedule v without the tail split
     v = v - 1000 if 1000 <= v < 2000 else v
     _lib.set_option("use_gemm256", 0 if v == 128 else (2 if v >= 400 else 1))  # 400 + a = 4-wave tile, ablation a
@@ -78,4 +85,4 @@ for r in range(args.rounds):
 valid_rows = M
 for name, (epi, K, N) in shapes.items():
     fl = 2.0 * valid_rows * K * N
-    print(name, "  ".join(f"v{v}: {fl / (sorted(res[(name, v)])[len(res[(name, v)]) // 2] * 1e-3) / 1e12:7.1f} TF (min {fl / (min(res[(name, v)]) * 1e-3) / 1e12:6.1f}..)" for v in variants))
+    print(name, "  ".join(f"v{v[0]}s{v[1]}: {fl / (sorted(res[(name, v)])[len(res[(name, v)]) // 2] * 1e-3) / 1e12:7.1f} TF (min {fl / (min(res[(name, v)]) * 1e-3) / 1e12:6.1f}..)" for v in variants))
