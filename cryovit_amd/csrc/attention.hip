@@ -64,22 +64,20 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qp + (long)qrow * ldqk + 16 * ks + 8 * h);
 
     // LDS-DMA source offsets for this thread's two 16-B pieces of each tile
-    int srow[2], schunk[2];
+    // (saddr-form DMA, common.h: wave-uniform tile base + tile-invariant 32-bit lane byte offsets -- no address VALU per piece)
+    uint32_t koffs[2], voffs[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const int c = jj * ATT_THREADS + tid;
-        srow[jj] = c >> 3;
-        schunk[jj] = ((c & 7) ^ ((srow[jj] >> 1) & 7)) << 3;
+        const int srow = c >> 3, schunk = ((c & 7) ^ ((srow >> 1) & 7)) << 3;
+        koffs[jj] = (uint32_t)(srow * ldqk + schunk) * 2u;
+        voffs[jj] = (uint32_t)(srow * kp + schunk) * 2u;
     }
     auto issue = [&](int j, int buf) {
-        char* kt = smem + buf * 2 * ATT_TILE_BYTES;
-        char* vtile = kt + ATT_TILE_BYTES;
+        const uint32_t kt = lds_addr(smem) + buf * 2 * ATT_TILE_BYTES + wave * 1024;
         const long kv0 = (long)j * KV_TILE;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            glds16(Kp + (kv0 + srow[jj]) * ldqk + schunk[jj], kt + (jj * ATT_THREADS + wave * 64) * 16);
-            glds16(Vp + (long)srow[jj] * kp + kv0 + schunk[jj], vtile + (jj * ATT_THREADS + wave * 64) * 16);
-        }
+        glds16_saddr2<ATT_THREADS * 16>(Kp + kv0 * ldqk, koffs[0], koffs[1], kt);
+        glds16_saddr2<ATT_THREADS * 16>(Vp + kv0, voffs[0], voffs[1], kt + ATT_TILE_BYTES);
     };
 
     // fragment read offsets
@@ -242,22 +240,22 @@ __global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restr
     }
     // LDS-DMA: 512 16-B pieces per K tile and per V^T tile, NT threads
     constexpr int NP = (512 + NT - 1) / NT;
-    int srow[NP], schunk[NP];
+    uint32_t koffs[NP], voffs[NP];
 #pragma unroll
     for (int jj = 0; jj < NP; ++jj) {
         const int c = jj * NT + tid;
-        srow[jj] = (c >> 3) & 63;
-        schunk[jj] = ((c & 7) ^ ((srow[jj] >> 1) & 7)) << 3;
+        const int srow = (c >> 3) & 63, schunk = ((c & 7) ^ ((srow >> 1) & 7)) << 3;
+        koffs[jj] = (uint32_t)(srow * ldqk + schunk) * 2u;
+        voffs[jj] = (uint32_t)(srow * kp + schunk) * 2u;
     }
     auto issue = [&](int j, int buf) {
-        char* kt = smem + buf * 2 * ATT_TILE_BYTES;
-        char* vtile = kt + ATT_TILE_BYTES;
+        const uint32_t kt = lds_addr(smem) + buf * 2 * ATT_TILE_BYTES;
         const long kv0 = (long)j * KV_TILE;
 #pragma unroll
         for (int jj = 0; jj < NP; ++jj) {
             if (jj * NT + wave * 64 >= 512) break;  // wave-uniform: the last pass may cover only some waves
-            glds16(Kp + (kv0 + srow[jj]) * ldqk + schunk[jj], kt + (jj * NT + wave * 64) * 16);
-            glds16(Vp + (long)srow[jj] * kp + kv0 + schunk[jj], vtile + (jj * NT + wave * 64) * 16);
+            glds16_saddr(Kp + kv0 * ldqk, koffs[jj], kt + (jj * NT + wave * 64) * 16);
+            glds16_saddr(Vp + kv0, voffs[jj], kt + ATT_TILE_BYTES + (jj * NT + wave * 64) * 16);
         }
     };
     const int krow = pi_row(r);

@@ -81,7 +81,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
     const int total = 4 * nk;
 
     // ---- LDS-DMA source offsets: 2 x 16-B pieces per thread per half-tile ----
-    uint32_t offR[2][2], offL[2][2];  // [half][piece], elements relative to the tile origin, K tile 0
+    uint32_t offR[2][2], offL[2][2];  // [half][piece], BYTES relative to the tile origin, K tile 0 (saddr-form DMA, common.h)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = j * G256_THREADS + tid;
@@ -89,9 +89,9 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int tr = (hr >> 5) * 64 + half * 32 + (hr & 31);   // R tile row: wave hr>>5, rows [32*half, +32)
-            offR[half][j] = (uint32_t)(sigma_row<4>(tr) * ldr + ch);
+            offR[half][j] = (uint32_t)(sigma_row<4>(tr) * ldr + ch) * 2u;
             const int tl = (hr >> 6) * 128 + half * 64 + (hr & 63);  // L tile row: wave hr>>6, rows [64*half, +64)
-            offL[half][j] = (uint32_t)(tl * ldl + ch);
+            offL[half][j] = (uint32_t)(tl * ldl + ch) * 2u;
         }
     }
     const uint16_t* Rb = Rmat + r0 * ldr;
@@ -107,7 +107,7 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
         int kt = ABL_SAME_K ? 0 : (q >> 2) + koff;
         if (kt >= nk) kt -= nk;
         const int kind = q & 3;
-        char* dst = smem + (q & 7) * G256_HALF_BYTES + wave * 1024;
+        const uint32_t dst = lds_addr(smem) + (q & 7) * G256_HALF_BYTES + wave * 1024;
         // slot order inside a K tile: variants 0-5: R-lo, L-lo, R-hi, L-hi;  variant 6: R-lo, R-hi, L-lo, L-hi
         const bool isL = VARIANT == 6 ? (kind >= 2) : (kind & 1);
         const int half = VARIANT == 6 ? (kind & 1) : (kind >> 1);
@@ -115,12 +115,10 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
         const uint32_t o0 = isL ? offL[half][0] : offR[half][0];
         const uint32_t o1 = isL ? offL[half][1] : offR[half][1];
         if (ABL_NO_R_DMA && !isL) {  // keep the vmcnt arithmetic: two cheap L2-resident pieces instead
-            glds16(Lb + o0 % 64, dst);
-            glds16(Lb + o1 % 64, dst + G256_THREADS * 16);
+            glds16_saddr2<G256_THREADS * 16>(Lb, o0 % 128, o1 % 128, dst);
             return;
         }
-        glds16(src + o0, dst);
-        glds16(src + o1, dst + G256_THREADS * 16);
+        glds16_saddr2<G256_THREADS * 16>(src, o0, o1, dst);
     };
 
     // ---- fragment read offsets inside a half-tile (k-step 0; k-step 1 = ^64) ----

@@ -9,8 +9,8 @@
 //     of the next tile in flight.  Its staging buffers are the three ring slots of the finished tile that no DMA targets
 //     until the next tile's first phase (L-lo, R-hi, L-hi of the last K tile: 48 KiB, 6 KiB per wave);
 //   * `vmcnt` retires loads, stores and LDS-DMA together IN ISSUE ORDER, so the S stores a wave issues in the epilogue (and
-//     the one constants piece, below) sit between half-tile 4 and half-tile 5 of the next tile in its queue: the first three
-//     counted waits of that tile's first K tile are 4+S / 5+S / 7+S instead of 4 / 4 / 6.  S is exact only when every store executes, i.e. for
+//     the constants pieces, below) sit between half-tile 4 and half-tile 5 of the next tile in its queue: the first three
+//     counted waits of that tile's first K tile are 4+S / 4+S+NC / 6+S+NC instead of 4 / 4 / 6.  S is exact only when every store executes, i.e. for
 //     launches whose tiles are all interior (FULL: M % 256 == 0, no padded output columns): there the stores are
 //     unpredicated.  Other launches keep predicated stores and the conservative 4 / 4 / 6 (correct, they only over-wait).
 //
@@ -23,7 +23,7 @@
 
 namespace cvx {
 
-constexpr int G256P_LDS_BYTES = G256_LDS_BYTES + 8 * 1024;  // ring + one 1-KiB constants piece per wave
+constexpr int G256P_LDS_BYTES = G256_LDS_BYTES + 8 * 2048;  // ring + two 1-KiB constants pieces (bias, gamma) per wave
 
 // vector-memory operations ONE wave issues in the staged epilogue of one interior tile and that may still be in flight
 // when the next tile starts (the residual epilogue's loads are consumed, hence complete, before its last stores)
@@ -107,35 +107,31 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
     Rn = Rc; Ln = Lc;
     if (id + per < cnt) panels(id + per, Rn, Ln, rn, ln);
 
-    // Per-column constants of the epilogue (bias, LayerScale gamma) reach the wave through one LDS-DMA piece per tile, issued
-    // in the tile's FIRST K tile into a 1-KiB slot behind the ring: a register load in the epilogue would be the YOUNGEST entry
-    // of the in-order vmcnt queue, and waiting for it would drain the five half-tiles in flight for the next tile.
-    // Piece layout: lanes 0-15 bias[nw + 4 l ..], lanes 16-31 gamma[..] (bias again when the epilogue has no gamma), 32-63 unused.
-    char* cbuf = smem + G256_LDS_BYTES + wave * 1024;
+    // Per-column constants of the epilogue (bias, LayerScale gamma) reach the wave through LDS-DMA pieces issued in the tile's
+    // FIRST K tile into 1-KiB slots behind the ring: a register load in the epilogue would be the YOUNGEST entry of the
+    // in-order vmcnt queue, and waiting for it would drain the five half-tiles in flight for the next tile.
+    // One piece per vector: lanes 0-15 carry the wave's 64 columns (16 B each), the other lanes re-read the same bytes.
+    constexpr int NC = epi_has_preload<Epi>::value ? 2 : 1;
+    char* cbuf = smem + G256_LDS_BYTES + wave * 2048;
     auto issue_consts = [&](long rr) {
         int l2 = tid & 63;
         asm volatile("" : "+v"(l2));
-        const float* src = epi.bias;
-        if constexpr (epi_has_preload<Epi>::value) src = (l2 & 16) ? epi.gamma : epi.bias;
-        glds16(src + rr + wr * 64 + 4 * (l2 & 15), cbuf);
+        const uint32_t voff = (uint32_t)(l2 & 15) * 16u;
+        glds16_saddr(epi.bias + rr + wr * 64, voff, lds_addr(cbuf));
+        if constexpr (epi_has_preload<Epi>::value) glds16_saddr(epi.gamma + rr + wr * 64, voff, lds_addr(cbuf) + 1024);
     };
 
     int slot0 = 0;  // ring slot of the current tile's half-tile 0 (0 or 4)
     // One LDS-DMA half-tile = two 1-KiB pieces per wave.  The source is a wave-uniform byte pointer (SGPR pair) + a 32-bit
-    // per-lane byte offset, the form hipcc lowers to `global_load_lds_dwordx4 voff, s[base]` without any per-piece VALU work;
+    // per-lane byte offset (glds16_saddr2, common.h: `global_load_lds_dwordx4 voff, s[base]`, no per-piece VALU work);
     // `slot` is the ring slot counted from the K tile's own group (values 5..8 = the next K tile's L-lo, R-hi, L-hi and the
     // R-lo after that).  Everything that could be selected at run time per piece (which tile, which K tile) is decided by the
     // CALLER once per K tile: scalar work in the MFMA segments is on the loop's critical path (measured: 25 extra SALU
     // instructions per K tile cost 135 of 2810 cycles).
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(CVX_LDS_AS char*)smem + wave * 1024;  // LDS byte address of this wave's piece in slot 0
+    const uint32_t lds0 = lds_addr(smem) + wave * 1024;  // LDS byte address of this wave's first piece in ring slot 0
     auto dma = [&](const char* src, const uint32_t (&off)[2], const char* st, int slot) {
         const uint32_t dst = lds0 + (((uint32_t)(st - smem) + slot * G256_HALF_BYTES) & (G256_LDS_BYTES - 1));
-        // saddr form (SGPR base + 32-bit lane offset): no address VALU at all; M0 (the LDS destination) is written in the same
-        // statement that uses it (hipcc does not preserve it across statements); one wait state between an SALU write of M0
-        // and the LDS-DMA that reads it
-        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-                     "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "v"(off[0]), "v"(off[1]), "s"(src), "s"(dst) : "memory");
+        glds16_saddr2<G256_THREADS * 16>(src, off[0], off[1], dst);
     };
     const int sw = (lane & 15) >> 1;
     const int fo = (lane & 15) * 128 + (((lane >> 4) ^ sw) << 4);
@@ -184,18 +180,18 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
         read_l(st + G256_HALF_BYTES);
         wait_vmcnt<4 + E>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (FIRST) issue_consts(r0);            // (one more entry between the epilogue's stores and half-tile 5)
+        if constexpr (FIRST) issue_consts(r0);            // (NC more entries between the epilogue's stores and half-tile 5)
         dma(Lk1, offL[0], st, 5);
         mma(rlo, 0, 0, first_tag);
         __builtin_amdgcn_s_barrier();
         read_r(rhi, st + 2 * G256_HALF_BYTES);            // ---- phase 1: (R-hi, L-lo) ----
-        wait_vmcnt<4 + E + (FIRST ? 1 : 0)>();
+        wait_vmcnt<4 + E + (FIRST ? NC : 0)>();
         __builtin_amdgcn_s_barrier();
         dma(Rk1, offR[1], st, 6);
         mma(rhi, 2, 0, first_tag);
         __builtin_amdgcn_s_barrier();
         read_l(st + 3 * G256_HALF_BYTES);                 // ---- phase 2: (R-hi, L-hi) ----
-        wait_vmcnt<6 + E + (FIRST ? 1 : 0)>();
+        wait_vmcnt<6 + E + (FIRST ? NC : 0)>();
         __builtin_amdgcn_s_barrier();
         dma(Lk1, offL[1], st, 7);
         mma(rhi, 2, 4, first_tag);
@@ -240,7 +236,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
             const float4 t = *(const float4*)(cbuf + (gq * 16 + 4 * f) * 4);
             ctx.bias[f * 4 + 0] = t.x; ctx.bias[f * 4 + 1] = t.y; ctx.bias[f * 4 + 2] = t.z; ctx.bias[f * 4 + 3] = t.w;
             if constexpr (epi_has_preload<Epi>::value) {
-                const float4 u = *(const float4*)(cbuf + 256 + (gq * 16 + 4 * f) * 4);
+                const float4 u = *(const float4*)(cbuf + 1024 + (gq * 16 + 4 * f) * 4);
                 ctx.gamma[f * 4 + 0] = u.x; ctx.gamma[f * 4 + 1] = u.y; ctx.gamma[f * 4 + 2] = u.z; ctx.gamma[f * 4 + 3] = u.w;
             }
         }

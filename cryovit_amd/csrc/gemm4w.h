@@ -44,19 +44,19 @@ __device__ __forceinline__ void gemm4w_body(const uint16_t* __restrict__ Rmat, l
     for (int i = 0; i < 4; ++i) {
         const int row = (i * 4 + wave) * 16 + (lane >> 2);  // LDS row of this lane's 16-B piece
         const int ch = ((lane & 3) ^ swz64(row)) << 3;      // source chunk (elements)
-        offR[i] = (uint32_t)(sigma_row<4>(row) * ldr + ch);
-        offL[i] = (uint32_t)(row * ldl + ch);
+        offR[i] = (uint32_t)(sigma_row<4>(row) * ldr + ch) * 2u;  // bytes (saddr-form DMA)
+        offL[i] = (uint32_t)(row * ldl + ch) * 2u;
     }
     const uint16_t* Rb = Rmat + r0 * ldr;
     const uint16_t* Lb = Lmat + l0 * ldl;
     auto issue = [&](int j) {  // sub-stage j -> ring slot j & 3
-        char* dst = smem + (j & (G4W_RING - 1)) * G4W_SUB_BYTES;
+        const uint32_t dst = lds_addr(smem) + (j & (G4W_RING - 1)) * G4W_SUB_BYTES;
         const uint16_t* rs = Rb + j * G4W_KS;
         const uint16_t* ls = Lb + j * G4W_KS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(rs + offR[i], dst + (i * 4 + wave) * 1024);
+        for (int i = 0; i < 4; ++i) glds16_saddr(rs, offR[i], dst + (i * 4 + wave) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(ls + offL[i], dst + 16384 + (i * 4 + wave) * 1024);
+        for (int i = 0; i < 4; ++i) glds16_saddr(ls, offL[i], dst + 16384 + (i * 4 + wave) * 1024);
     };
 
     // ---- fragment reads: frag f of the wave's 128 rows: row = w*128 + f*16 + (lane&15), chunk = (lane>>4) ^ swz ----
@@ -95,7 +95,7 @@ __device__ __forceinline__ void gemm4w_body(const uint16_t* __restrict__ Rmat, l
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const bool do_issue = VARIANT != 1 && (STEADY || j + 4 < nks), do_read = STEADY || j + 1 < nks;
-        char* dst = smem + ((j + 4) & (G4W_RING - 1)) * G4W_SUB_BYTES;
+        const uint32_t dst = lds_addr(smem) + ((j + 4) & (G4W_RING - 1)) * G4W_SUB_BYTES;
         const char* nst = smem + ((j + 1) & (G4W_RING - 1)) * G4W_SUB_BYTES;
         const uint16_t* rs = Rb + (VARIANT == 2 ? 0 : (j + 4) * G4W_KS);  // VARIANT 1/2: timing-only ablations (no DMA / L2-resident DMA)
         const uint16_t* ls = Lb + (VARIANT == 2 ? 0 : (j + 4) * G4W_KS);
@@ -103,8 +103,8 @@ __device__ __forceinline__ void gemm4w_body(const uint16_t* __restrict__ Rmat, l
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             if (do_issue) {
-                if (a < 4) glds16(rs + offR[a], dst + (a * 4 + wave) * 1024);
-                else glds16(ls + offL[a - 4], dst + 16384 + ((a - 4) * 4 + wave) * 1024);
+                if (a < 4) glds16_saddr(rs, offR[a], dst + (a * 4 + wave) * 1024);
+                else glds16_saddr(ls, offL[a - 4], dst + 16384 + ((a - 4) * 4 + wave) * 1024);
             }
             if (do_read) {
                 nr[a] = *(const bf16x8*)(nst + foR + a * 1024);

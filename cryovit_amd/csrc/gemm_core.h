@@ -46,7 +46,7 @@ template <int ROWS, int FRG>
 struct PlainLoader {
     static constexpr int NJ = (ROWS * 8 + GEMM_THREADS - 1) / GEMM_THREADS;
     const uint16_t* base;  // tile origin: matrix + row0*ld
-    uint32_t off[NJ];      // per-thread element offsets (row*ld + chunk*8)
+    uint32_t off[NJ];      // per-thread BYTE offsets (row*ld + chunk*8) * 2: saddr-form LDS-DMA (common.h)
     int wave;
 
     __device__ __forceinline__ void init(const uint16_t* mat, long ld, long row0, int tid) {
@@ -56,7 +56,7 @@ struct PlainLoader {
         for (int j = 0; j < NJ; ++j) {
             const int c = j * GEMM_THREADS + tid;
             const int row = c >> 3, pos = c & 7;
-            off[j] = (uint32_t)(sigma_row<FRG>(row) * ld + ((pos ^ swz_chunk(row)) << 3));
+            off[j] = (uint32_t)(sigma_row<FRG>(row) * ld + ((pos ^ swz_chunk(row)) << 3)) * 2u;
         }
     }
     __device__ __forceinline__ void issue(char* lds_tile, int kt) const {
@@ -64,7 +64,7 @@ struct PlainLoader {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if ((ROWS * 8) % GEMM_THREADS != 0 && (j * GEMM_THREADS + wave * 64) >= ROWS * 8) break;
-            glds16(b + off[j], lds_tile + (j * GEMM_THREADS + wave * 64) * 16);
+            glds16_saddr(b, off[j], lds_addr(lds_tile) + (j * GEMM_THREADS + wave * 64) * 16);
         }
     }
 };
@@ -112,7 +112,7 @@ struct Conv3Loader {
             const bool ok = rowok[j] && tap < 27 && (unsigned)zz < (unsigned)D && (unsigned)yy < (unsigned)H &&
                             (unsigned)xx < (unsigned)W;
             const uint16_t* g = ok ? in + (((long)zz * H + yy) * W + xx) * C + c : zero;
-            glds16(g, lds_tile + (j * GEMM_THREADS + wave * 64) * 16);
+            glds16_vaddr(g, lds_addr(lds_tile) + (j * GEMM_THREADS + wave * 64) * 16);
         }
     }
 };
@@ -171,7 +171,10 @@ __device__ __forceinline__ void gemm_tile_body(const LoaderR& ldr, const LoaderL
 
     ldr.issue(smem, 0);
     ldl.issue(smem + Cfg::TILE_R_BYTES, 0);
-    __syncthreads();  // hipcc drains vmcnt(0) here: the LDS-DMA has landed
+    // the LDS-DMA is issued from inline asm (saddr form, common.h), which hipcc's own vmcnt bookkeeping does not see:
+    // the drain before the barrier is explicit
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         char* cur = smem + (kt & 1) * Cfg::STAGE_BYTES;
@@ -193,7 +196,8 @@ __device__ __forceinline__ void gemm_tile_body(const LoaderR& ldr, const LoaderL
                 for (int b = 0; b < FL; ++b)
                     acc[a][b] = mfma16x16x32<epi_is_f16<Epi>::value>(rf[a], lf[b], acc[a][b]);
         }
-        __syncthreads();  // next tile landed (vmcnt(0)) and everyone is done reading `cur`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // next tile landed and everyone is done reading `cur`
     }
 
     // epilogue: lane (g = lane>>4) owns R rows [g*4*FRG, +4*FRG) of each 16*FRG-row group, one L row per frag
