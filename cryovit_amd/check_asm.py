@@ -1,0 +1,70 @@
+"""Static check of the persistent GEMM tile kernels (csrc/gemm256p.h) in the emitted gfx950 assembly.
+
+The kernel counts its own vector-memory operations in hand-written ``s_waitcnt vmcnt(N)`` waits, so three properties of
+the COMPILED code are part of its correctness and are asserted here (``python -m cryovit_amd.check_asm``, run by the CPU
+test suite -- hipcc cross-compiles without a GPU):
+
+  * no scratch: a register spill is a scratch store / load, i.e. an uncounted entry in the in-order vmcnt queue;
+  * the epilogue of an interior-tile ("FULL") kernel issues exactly ``epi_stores_per_wave`` global stores (8 SwiGLU, 16 bf16 /
+    fp16, 32 fp32) -- hipcc splits and merges the stores it generates itself, the kernel's come from inline asm;
+  * every LDS-DMA is the inline-asm saddr form (``global_load_lds_dwordx4 vOFF, s[BASE]``): the builtin form would let hipcc
+    cache what it believes M0 holds across the asm statements that rewrite it.
+"""
+
+from __future__ import annotations
+
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+from cryovit_amd.build import ARCH, CSRC, FILE_FLAGS, FLAGS, INCLUDE, hipcc_path
+
+EXPECTED_STORES = {"EpiSwiGLU": 8, "EpiBF16": 16, "EpiResidT": 32}
+
+
+def compile_asm(src: Path) -> str:
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / (src.stem + ".s")
+        flags = [f for f in FLAGS if f != "-fPIC"]
+        cmd = [hipcc_path(), *flags, *FILE_FLAGS.get(src.name, []), "-I", str(INCLUDE), "-S", "--cuda-device-only", "-o", str(out), str(src)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc -S failed on {src.name}:\n{r.stderr}")
+        return out.read_text()
+
+
+def check_gemm256p(asm: str) -> list[str]:
+    """One line per persistent kernel: name, VGPRs, stores; raises AssertionError on a violated property."""
+    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(_ZN3cvx15k_gemm256p_nreg\w+):.*?\n(.*?)s_endpgm", asm, re.S | re.M)}
+    assert bodies, "no k_gemm256p_nreg kernels in the assembly"
+    report = []
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN3cvx15k_gemm256p_nreg\w+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+        name, desc = m.group(1), m.group(2)
+        body = bodies[name]
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1))
+        assert scratch == 0 and "scratch_" not in body, f"{name}: spills to scratch ({scratch} B): uncounted vmcnt entries"
+        assert vgpr <= 256, f"{name}: {vgpr} VGPRs"
+        dma = re.findall(r"global_load_lds_dwordx4 (.*)", body)
+        assert dma and all(re.fullmatch(r"v\d+, s\[\d+:\d+\]", d.strip()) for d in dma), f"{name}: LDS-DMA not in saddr form: {set(dma)}"
+        stores = len(re.findall(r"global_store_", body))
+        full = re.search(r"ELb1ELb[01]EEEv", name) is not None  # template args <Epi, FULL = true, DBG>
+        kind = next(k for k in EXPECTED_STORES if k in name)
+        if full:
+            assert stores == EXPECTED_STORES[kind], f"{name}: {stores} store instructions, the waits assume {EXPECTED_STORES[kind]}"
+            assert all(s.startswith("global_store_dwordx4") for s in re.findall(r"global_store_\w+", body)), name
+        report.append(f"{name[24:70]:48s} vgpr {vgpr:3d} stores {stores:2d} dma {len(dma):2d} {'FULL' if full else 'edge'}")
+    return report
+
+
+def main() -> None:
+    for line in check_gemm256p(compile_asm(CSRC / "gemm.hip")):
+        print(line)
+    print("ok")
+
+
+if __name__ == "__main__":
+    assert ARCH == "gfx950"
+    main()

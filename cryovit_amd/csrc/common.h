@@ -112,6 +112,16 @@ __device__ __forceinline__ void st_stream(uint16_t* p, const uint4& v) {
     if (g_stream_io) __builtin_nontemporal_store(t, (u32x4*)p); else *(u32x4*)p = t;
 }
 
+// 16-B stores in saddr form issued from inline asm: ONE store instruction per call, guaranteed (hipcc may split or merge the
+// stores it generates itself -- a `*(uint4*)p = v` came out as two dwordx2 -- and the persistent GEMM tile counts its stores
+// in hand-written vmcnt waits).  The trailing s_nop keeps the next VALU write of the data registers behind the store's read.
+__device__ __forceinline__ void gst16_saddr(void* sbase, uint32_t voff, const u32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void gst16_saddr_nt(void* sbase, uint32_t voff, const u32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

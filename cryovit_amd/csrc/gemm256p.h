@@ -23,6 +23,7 @@
 
 namespace cvx {
 
+constexpr bool DIRECT8 = true;  // SwiGLU epilogue: store straight from the accumulator layout (A/B switch for tools/)
 constexpr int G256P_LDS_BYTES = G256_LDS_BYTES + 8 * 2048;  // ring + two 1-KiB constants pieces (bias, gamma) per wave
 
 // vector-memory operations ONE wave issues in the staged epilogue of one interior tile and that may still be in flight
@@ -291,7 +292,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                     if (FULL || (16 * u + 4 * i + mrow < mleft && nok)) {
                         float4 o;
                         o.x = xq4.x + d.x; o.y = xq4.y + d.y; o.z = xq4.z + d.z; o.w = xq4.w + d.w;
-                        st_stream((float*)(xu + loff[i]), o);
+                        gst16_saddr_nt(xu, loff[i], __builtin_bit_cast(u32x4, o));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -309,6 +310,25 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
             uint32_t loff[32 / RPI];
 #pragma unroll
             for (int i = 0; i < 32 / RPI; ++i) loff[i] = ((uint32_t)(RPI * i + srow) * ldc + (uint32_t)(spiece * 8)) * 2u;  // BYTES
+            if constexpr (O16 == 8 && DIRECT8) {
+                // 8 packed outputs = 16 B per lane: in accumulator layout a wave instruction already writes 16 rows x 64
+                // contiguous bytes (the four lane groups of a row sit side by side) -- the same shape the staged path
+                // produces, without the LDS round trip
+                const uint32_t doff = ((uint32_t)(lane & 15) * ldc + (uint32_t)(gq * 8)) * 2u;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    float v[16];
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][b][e];
+                    uint32_t w[O16 / 2];
+                    epi.produce(ctx, v, w);
+                    char* ob = (char*)(outw + (long)(16 * b) * ldc);
+                    if (FULL || (16 * b + (lane & 15) < mleft && ow + gq * 8 < (epi.n_valid >> Epi::OUT_SHIFT)))
+                        gst16_saddr(ob, doff, u32x4{w[0], w[1], w[2], w[3]});
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 char* oq = (char*)(outw + (long)(32 * q) * ldc);
@@ -334,8 +354,8 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                     const int row = RPI * i + srow;
                     const uint4 d = *(const uint4*)(stg + row * PITCHB + spiece * 16);
                     if (FULL || (32 * q + row < mleft && ook)) {
-                        if constexpr (O16 == 16) st_stream((uint16_t*)(oq + loff[i]), d);
-                        else *(uint4*)(oq + loff[i]) = d;  // 64-B segments: left to the L2's write combining
+                        if constexpr (O16 == 16) gst16_saddr_nt(oq, loff[i], u32x4{d.x, d.y, d.z, d.w});
+                        else gst16_saddr(oq, loff[i], u32x4{d.x, d.y, d.z, d.w});  // 64-B segments: left to the L2's write combining
                     }
                 }
             }

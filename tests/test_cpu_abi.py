@@ -63,3 +63,14 @@ def test_product_never_imports_oracle():
     for f in (ROOT / "cryovit_amd").rglob("*.py"):
         src = f.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_persistent_gemm_kernels_static_properties():
+    """The persistent GEMM tile counts its own vector-memory operations in hand-written vmcnt waits: no spill, an exact
+    number of epilogue stores and saddr-form LDS-DMA in the COMPILED gfx950 code are part of its correctness
+    (cryovit_amd/check_asm.py; hipcc cross-compiles here without a GPU, ~90 s)."""
+    from cryovit_amd import check_asm
+    from cryovit_amd.build import CSRC
+
+    report = check_asm.check_gemm256p(check_asm.compile_asm(CSRC / "gemm.hip"))
+    assert len(report) >= 10 and any("EpiSwiGLU" in r and "FULL" in r for r in report)
