@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import os  # noqa: E402
 
-os.environ.setdefault("CVX_ABLATION_LIB", "1")  # the timing-only variants live in the -DCVX_ABLATION build only
+os.environ.setdefault("CVX_ABLATION_LIB", "1")  # CVX_ABLATION_LIB=0: the product library (profiles of the shipped kernel)
 from cryovit_amd import _lib  # noqa: E402
 from cryovit_amd.build import build_library  # noqa: E402
 
