@@ -21,7 +21,7 @@ from pathlib import Path
 
 from cryovit_amd.build import ARCH, CSRC, FILE_FLAGS, FLAGS, INCLUDE, hipcc_path
 
-EXPECTED_STORES = {"EpiSwiGLU": 8, "EpiBF16": 16, "EpiResidT": 32}
+EXPECTED_STORES = {"EpiSwiGLU": 8, "EpiBF16": 16, "EpiResidT": 32, "EpiVT": 16}
 
 
 def compile_asm(src: Path) -> str:
@@ -37,10 +37,10 @@ def compile_asm(src: Path) -> str:
 
 def check_gemm256p(asm: str) -> list[str]:
     """One line per persistent kernel: name, VGPRs, stores; raises AssertionError on a violated property."""
-    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(_ZN3cvx15k_gemm256p_nreg\w+):.*?\n(.*?)s_endpgm", asm, re.S | re.M)}
-    assert bodies, "no k_gemm256p_nreg kernels in the assembly"
+    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(_ZN3cvx15k_gemm256p_[nm]reg\w+):.*?\n(.*?)s_endpgm", asm, re.S | re.M)}
+    assert bodies, "no k_gemm256p kernels in the assembly"
     report = []
-    for m in re.finditer(r"\.amdhsa_kernel (_ZN3cvx15k_gemm256p_nreg\w+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+    for m in re.finditer(r"\.amdhsa_kernel (_ZN3cvx15k_gemm256p_[nm]reg\w+)(.*?)\.end_amdhsa_kernel", asm, re.S):
         name, desc = m.group(1), m.group(2)
         body = bodies[name]
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1))
@@ -50,7 +50,7 @@ def check_gemm256p(asm: str) -> list[str]:
         dma = re.findall(r"global_load_lds_dwordx4 (.*)", body)
         assert dma and all(re.fullmatch(r"v\d+, s\[\d+:\d+\]", d.strip()) for d in dma), f"{name}: LDS-DMA not in saddr form: {set(dma)}"
         stores = len(re.findall(r"global_store_", body))
-        full = re.search(r"ELb1ELb[01]EEEv", name) is not None  # template args <Epi, FULL = true, DBG>
+        full = re.search(r"ELb1E(Lb[01]E)?EEv", name) is not None  # template args <Epi, FULL = true[, DBG]>
         kind = next(k for k in EXPECTED_STORES if k in name)
         if full:
             assert stores == EXPECTED_STORES[kind], f"{name}: {stores} store instructions, the waits assume {EXPECTED_STORES[kind]}"

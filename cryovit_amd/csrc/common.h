@@ -122,6 +122,10 @@ __device__ __forceinline__ void gst16_saddr_nt(void* sbase, uint32_t voff, const
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
+__device__ __forceinline__ void gst16_vaddr(void* p, const u32x4& v) {  // per-lane 64-bit address
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

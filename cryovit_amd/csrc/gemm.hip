@@ -202,6 +202,21 @@ struct EpiVT {
     template <int NV> struct Ctx {};
     template <int NV>
     __device__ __forceinline__ void prep(Ctx<NV>&, long) const {}
+    // persistent tile (gemm256p.h): 16 consecutive token rows m0.. of feature n, bias already added; exactly two 16-B stores
+    // (inline asm) when UNPREDICATED (interior tiles: every row and feature is inside the problem)
+    static constexpr bool MREG16 = true;
+    template <bool UNPREDICATED>
+    __device__ __forceinline__ void store16(long m0, long n, const float* v) const {
+        const long head = n >> 6, d = n & 63;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long m8 = m0 + h * 8 + m_off;
+            const long s = m8 / ntp, t = m8 - s * ntp;  // ntp % 8 == 0: a group of 8 never straddles slices
+            const u32x4 w{pack2bf(v[h * 8 + 0], v[h * 8 + 1]), pack2bf(v[h * 8 + 2], v[h * 8 + 3]), pack2bf(v[h * 8 + 4], v[h * 8 + 5]),
+                          pack2bf(v[h * 8 + 6], v[h * 8 + 7])};
+            if (UNPREDICATED || (m0 + h * 8 < m_valid && n < n_valid)) gst16_vaddr(vt + ((s * heads + head) * 64 + d) * (long)kp + t, w);
+        }
+    }
     template <int NV>
     __device__ __forceinline__ void store(const Ctx<NV>&, long m0, long n, const float* acc) const {
         static_assert(NV % 8 == 0, "V^T epilogue stores 8 tokens (16 B) at a time");
@@ -324,6 +339,13 @@ __global__ __launch_bounds__(G256_THREADS) void k_gemm256p_nreg(const uint16_t* 
     gemm256p_body<Epi, FULL, DBG>(Wt, ldw, A, lda, nk, tiles_n, tiles_m, group_l, xcd_stagger, epi, smem);
 }
 
+template <class Epi, bool FULL>
+__global__ __launch_bounds__(G256_THREADS) void k_gemm256p_mreg(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nk,
+                                                                 int tiles_n, int tiles_m, int group_l, int xcd_stagger, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm256p_body<Epi, FULL, false>(A, lda, Wt, ldw, nk, tiles_m, tiles_n, group_l, xcd_stagger, epi, smem);
+}
+
 // tuning switches (cvx_set_option): A/B the tile kernels and pipeline schedules inside ONE process
 static std::atomic<int> g_tile_group_l_host{8};  // host copy of g_tile_group_l (the persistent kernel takes it as an argument)
 static std::atomic<int> g_use_gemm256{1}, g_gemm256_variant{9}, g_gemm_stagger{0};  // 9 = persistent (gemm256p.h)  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
@@ -361,7 +383,7 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
         return cvx_check_launch();
     }
     const int variant = g_gemm256_variant;
-    if constexpr (!MREG && (epi_has_preload<Epi>::value || epi_has_produce<Epi>::value)) {
+    if constexpr ((!MREG && (epi_has_preload<Epi>::value || epi_has_produce<Epi>::value)) || (MREG && epi_is_mreg<Epi>::value)) {
         if (variant == 9 || variant == 29) {
             // one workgroup per CU (128 KiB of LDS each), a multiple of 8 so every XCD gets the same number
             static int n_cu = 0;
@@ -374,10 +396,15 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             const int ntiles = tiles_n * tiles_m;
             const int grid = ntiles >= n_cu ? n_cu : (ntiles + 7) / 8 * 8;
             const bool full = M % 256 == 0 && epi.n_valid == Npad;
-            auto kp = full ? k_gemm256p_nreg<Epi, true> : k_gemm256p_nreg<Epi, false>;
+            void (*kp)(const uint16_t*, long, const uint16_t*, long, int, int, int, int, int, Epi);
+            if constexpr (MREG) {
+                kp = full ? k_gemm256p_mreg<Epi, true> : k_gemm256p_mreg<Epi, false>;
+            } else {
+                kp = full ? k_gemm256p_nreg<Epi, true> : k_gemm256p_nreg<Epi, false>;
 #ifdef CVX_ABLATION
-            if (variant == 29) kp = k_gemm256p_nreg<Epi, true, true>;  // stamped (interior tiles only)
+                if (variant == 29) kp = k_gemm256p_nreg<Epi, true, true>;  // stamped (interior tiles only)
 #endif
+            }
             CVX_HIP(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS_BYTES));
             hipLaunchKernelGGL(kp, dim3(grid), dim3(G256_THREADS), G256P_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / BK), tiles_n, tiles_m,
                                (int)g_tile_group_l_host, ntiles > grid ? (int)g_gemm_stagger : 0, epi);

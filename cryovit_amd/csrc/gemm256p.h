@@ -28,8 +28,15 @@ constexpr int G256P_LDS_BYTES = G256_LDS_BYTES + 8 * 2048;  // ring + two 1-KiB 
 
 // vector-memory operations ONE wave issues in the staged epilogue of one interior tile and that may still be in flight
 // when the next tile starts (the residual epilogue's loads are consumed, hence complete, before its last stores)
+// MREG orientation (R = activation rows -> accumulator registers, L = weight rows -> lanes): a lane owns 16 consecutive ROWS of
+// one output feature; such epilogues (V^T for the attention kernel) declare `static constexpr bool MREG16 = true` and
+// `store16(m0, n, v)`, which issues exactly two 16-B stores
+template <class E, class = void> struct epi_is_mreg : std::false_type {};
+template <class E> struct epi_is_mreg<E, std::enable_if_t<E::MREG16>> : std::true_type {};
+
 template <class Epi> constexpr int epi_stores_per_wave() {
-    if constexpr (epi_has_preload<Epi>::value) return 32;                        // 4 x 8 float4 stores
+    if constexpr (epi_is_mreg<Epi>::value) return 16;                            // 8 fragments x 2 stores of 8 rows
+    else if constexpr (epi_has_preload<Epi>::value) return 32;                   // 4 x 8 float4 stores
     else return 4 * (32 / (64 / (4 * Epi::OUT16 * 2 / 16)));                      // 4 x (32 rows / rows per instruction)
 }
 
@@ -56,7 +63,8 @@ __device__ unsigned long long g_gemm256p_dbg[2 * 8 * 6];
 template <class Epi, bool FULL, bool DBG = false>
 __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat, long ldr, const uint16_t* __restrict__ Lmat, long ldl,
                                               int nk, int tiles_r, int tiles_l, int group_l, int xcd_stagger, const Epi& epi, char* smem) {
-    static_assert(epi_has_preload<Epi>::value || epi_has_produce<Epi>::value, "persistent tile: LDS-staged epilogues only");
+    constexpr bool MREG = epi_is_mreg<Epi>::value;
+    static_assert(MREG || epi_has_preload<Epi>::value || epi_has_produce<Epi>::value, "persistent tile: counted-store epilogues only");
     constexpr bool F16 = epi_is_f16<Epi>::value;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,6 +125,10 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
     auto issue_consts = [&](long rr) {
         int l2 = tid & 63;
         asm volatile("" : "+v"(l2));
+        if constexpr (MREG) {  // features sit on the L side: the wave's 128 features = lanes 0-31 x 16 B
+            glds16_saddr(epi.bias + rr + wl * 128, (uint32_t)(l2 & 31) * 16u, lds_addr(cbuf));
+            return;
+        }
         const uint32_t voff = (uint32_t)(l2 & 15) * 16u;
         glds16_saddr(epi.bias + rr + wr * 64, voff, lds_addr(cbuf));
         if constexpr (epi_has_preload<Epi>::value) glds16_saddr(epi.gamma + rr + wr * 64, voff, lds_addr(cbuf) + 1024);
@@ -181,7 +193,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
         read_l(st + G256_HALF_BYTES);
         wait_vmcnt<4 + E>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (FIRST) issue_consts(r0);            // (NC more entries between the epilogue's stores and half-tile 5)
+        if constexpr (FIRST) issue_consts(MREG ? l0 : r0);            // (NC more entries between the epilogue's stores and half-tile 5)
         dma(Lk1, offL[0], st, 5);
         mma(rlo, 0, 0, first_tag);
         __builtin_amdgcn_s_barrier();
@@ -231,6 +243,22 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
         asm volatile("" : "+v"(lane));
         char* stg_base = smem + (((slot0 >> 2) + nk - 1) & 1) * 4 * G256_HALF_BYTES + G256_HALF_BYTES + wave * 6144;
         const int gq = lane >> 4;
+        if constexpr (MREG) {
+            // lane group gq owns rows r0 + wr*64 + 16 gq .. +15 of feature l0 + wl*128 + 16 b + (lane & 15): 32 contiguous
+            // bytes of the transposed output per fragment, stored straight from the accumulator layout
+            const long m0 = r0 + wr * 64 + gq * 16;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int nl = b * 16 + (lane & 15);
+                const float bias = *(const float*)(cbuf + nl * 4);
+                float v[16];
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][b][e] + bias;
+                epi.template store16<FULL>(m0, l0 + wl * 128 + nl, v);
+            }
+        } else {
         typename Epi::template Ctx<16> ctx;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
@@ -360,10 +388,11 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                 }
             }
         }
+        }  // !MREG
     };
 
     // ---- pipeline fill (first tile only): half-tiles 0..4 = K tile 0 and R-lo of K tile 1 ----
-    issue_consts(r0);
+    issue_consts(MREG ? l0 : r0);
     dma((const char*)Rc, offR[0], smem, 0);
     dma((const char*)Lc, offL[0], smem, 1);
     dma((const char*)Rc, offR[1], smem, 2);
