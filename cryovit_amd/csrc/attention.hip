@@ -62,6 +62,23 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qp + (long)qrow * ldqk + 16 * ks + 8 * h);
+    // Scores arrive in LOG2 units: the caller folds head_dim^-0.5 * log2(e) into the Q projection (one rounding, at weight
+    // packing), so p = exp2(S - m) with no multiply.
+    // VARIANT 6: the running maximum is subtracted INSIDE the matrix product: a fifth
+    // k-step whose K operand is the constant column e_0 and whose Q operand carries -m of the lane's query row, so
+    //   S' = K Q^T - m   and   p = exp2(S')   with no per-element VALU work at all
+    // as long as the row maxima of the tile stay within DEFER (log2 units) of the value subtracted.  The VALU, not the
+    // matrix pipe, bounds this kernel at head_dim 64 (PMC: VALU active 73 % of SIMD cycles, MFMA 39 %); the 32 fused
+    // multiply-adds per tile this removes were 15 % of its vector instructions, for 2 more MFMAs on the idle pipe.
+    constexpr bool AUG = VARIANT == 6;
+    constexpr float DEFER = 3.0f;  // p <= 2^3 before a row's maximum is raised (bf16 P is floating point: same relative precision)
+    bf16x8 kaug, qaug;
+    [[maybe_unused]] float m_used = 0.f;  // what is currently subtracted (exactly representable in bf16)
+    if constexpr (AUG) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kaug[e] = (__bf16)0.f; qaug[e] = (__bf16)0.f; }
+        if (h == 0) kaug[0] = (__bf16)1.0f;
+    }
 
     // LDS-DMA source offsets for this thread's two 16-B pieces of each tile
     // (saddr-form DMA, common.h: wave-uniform tile base + tile-invariant 32-bit lane byte offsets -- no address VALU per piece)
@@ -89,7 +106,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const float LOG2E = 1.4426950408889634f;
+    const float LOG2E = 1.0f;  // (scores are already in log2 units: see the note at the Q fragments)
 
     const int nkv = (ntok + KV_TILE - 1) / KV_TILE;
     constexpr bool SKIP_RESCALE = VARIANT != 1, ABL_NOEXP = VARIANT == 10;
@@ -122,12 +139,14 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            if constexpr (AUG) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kaug, qaug, s[t], 0, 0, 0);  // -m_used for every key
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *(const bf16x8*)(kt + t * 4096 + koff + (((2 * ks + h) ^ ksw) << 4));
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
             }
+        }
 
         // ---- mask keys >= ntok (last tile only; wave-uniform test) ----
         const int kv0 = j * KV_TILE;
@@ -141,6 +160,39 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
                 }
         }
 
+        if constexpr (AUG) {
+            // ---- online softmax on S' = S - m_used (log2 units) ----
+            float mloc = s[0][0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, s[0][i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, s[1][i]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            // tile 0 anchors every row at its own maximum, whatever its sign (m_used starts at 0: a row whose scores are all
+            // far below zero must not underflow to l = 0); later tiles only ever raise it
+            if (j == 0 || __builtin_amdgcn_ballot_w64(mloc > DEFER) != 0) {
+                // the subtracted maximum becomes the row's new maximum rounded to bf16 (the value the next tiles' products
+                // subtract must be the one used here); delta is exact in fp32
+                const float m_new = (float)(__bf16)(m_used + (j == 0 ? mloc : fmaxf(mloc, 0.f)));
+                const float delta = m_new - m_used;
+                m_used = m_new;
+                if (h == 0) qaug[0] = (__bf16)(-m_new);
+                const float alpha = j == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);  // (tile 0: O = l = 0, and -delta may be huge)
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; s[0][i] -= delta; s[1][i] -= delta; }
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float p = __builtin_amdgcn_exp2f(s[t][i]);
+                    s[t][i] = p;
+                    psum += p;
+                }
+            l_run += psum;
+        } else {
         // ---- online softmax (scores already carry head_dim^-0.5 through Q) ----
         float mloc = s[0][0];
 #pragma unroll
@@ -167,6 +219,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
         }
+        }  // !AUG
 
         // ---- O^T[dt] += V^T[dt] P^T : accumulator registers 8s..8s+7 of S^T[t] are k-step s of the B operand ----
 #pragma unroll
@@ -268,7 +321,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o[g][0][i] = 0.f; o[g][1][i] = 0.f; }
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    const float LOG2E = 1.4426950408889634f;
+    const float LOG2E = 1.0f;  // (scores are already in log2 units: see the note at the Q fragments)
     const int nkv = (ntok + KV_TILE - 1) / KV_TILE;
 
     issue(0, 0);
@@ -372,7 +425,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restr
 
 using namespace cvx;
 
-std::atomic<int> g_attn_variant{0};     // cvx_set_option("attn_variant")
+std::atomic<int> g_attn_variant{6};     // cvx_set_option("attn_variant"); 6 = maximum subtracted inside the product (default)
 std::atomic<int> g_attn_xcd_remap{1};   // cvx_set_option("attn_xcd_remap")
 
 extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
@@ -391,6 +444,7 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     switch (variant) {
         case 1: k = k_attention<1>; break;
         case 3: k = k_attention<3>; break;
+        case 6: k = k_attention<6>; break;
 #ifdef CVX_ABLATION  // timing-only, garbage output
         case 10: k = k_attention<10>; break;
         case 11: k = k_attention<11>; break;

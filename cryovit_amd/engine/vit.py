@@ -8,7 +8,7 @@ resize of ``/root/reference/src/cryovit/datasets/vit_dataset.py:117-123`` and th
 Data layout in HBM (b slices, C channels, NT = hp*wp+1+n_reg tokens, NTP = NT rounded up to 8):
   x      fp32 [b*NTP (+pad)][C]   residual stream (row = slice*NTP + token; rows NT..NTP-1 are finite padding)
   xn     bf16 [..][C]             LayerNorm output = GEMM A operand
-  qk     bf16 [..][2C]            Q (pre-scaled by head_dim^-0.5) | K, token-major
+  qk     bf16 [..][2C]            Q (pre-scaled by head_dim^-0.5 * log2 e) | K, token-major
   vt     bf16 [b][heads][64][KP]  V transposed per head (KP = NT rounded up to 64), written by the V GEMM epilogue
   ao     bf16 [..][C]             attention output
   hid    bf16 [..][Hd_pad]        gated / activated FFN hidden
@@ -150,7 +150,9 @@ class VitEngine:
         w["norm_w"], w["norm_b"] = up(g("norm.weight")), up(g("norm.bias"))
         self.hid_pad = round_up(cfg.ffn_hidden, 64)
         blocks = []
-        scale = 64**-0.5  # exact power of two: folding it into bf16 weights is lossless
+        # head_dim^-0.5 * log2(e) folded into the Q rows in fp32 BEFORE the bf16 rounding: the attention kernel works in log2
+        # units (p = exp2(s - m), no per-score multiply; oracle/dinov2.py::forward_features_bf16_storage mirrors the rounding point)
+        scale = 64**-0.5 * math.log2(math.e)
         for i in range(cfg.depth):
             p = f"blocks.{i}."
             qkv_w, qkv_b = g(p + "attn.qkv.weight").clone(), g(p + "attn.qkv.bias").clone()

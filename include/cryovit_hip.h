@@ -110,7 +110,8 @@ int cvx_layernorm_bf16(const float* x, long ldx, const float* w, const float* b,
                        int C, float eps, hipStream_t stream);
 
 /* Multi-head attention, head_dim 64, no mask/dropout:  O = softmax(Q K^T) V  per (slice, head).
- *   qk   bf16 [slices*ntp (+64 rows slack)][ldqk] : columns [0,C) = Q (pre-scaled by head_dim^-0.5),
+ *   qk   bf16 [slices*ntp (+64 rows slack)][ldqk] : columns [0,C) = Q pre-scaled by head_dim^-0.5 * log2(e)
+ *                                                  (scores in log2 units: the kernel uses exp2),
  *                                                  [C,2C) = K, head h at columns h*64..h*64+63
  *   vt   bf16 [slices][heads][64][kp]  (kp = ntok rounded up to 64; columns >= ntok must be finite)
  *   out  bf16 [slices*ntp][ldo], head h at columns h*64...
@@ -214,7 +215,7 @@ int cvx_fpn_level_out(const float* lateral, const float* coarse, int slices, int
  * GEMM, `depth` x { LN, QK GEMM, V^T GEMM, attention, proj GEMM (LayerScale+residual), LN, FFN-in GEMM (SwiGLU gate or
  * GELU), FFN-out GEMM (LayerScale+residual) }, final LN + feature layouts.  Replaces the hub model's forward_features
  * (run/dino_features.py:58).  All pointers are device buffers owned by the caller; weights are packed as documented for
- * cvx_gemm_bf16 (Q rows pre-scaled by 1/8; W12 interleaved in blocks of 8 for the SwiGLU variant).
+ * cvx_gemm_bf16 (Q rows pre-scaled by log2(e)/8; W12 interleaved in blocks of 8 for the SwiGLU variant).
  * ------------------------------------------------------------------------------------------------- */
 typedef struct cvx_vit_layer {
     const float *ln1_w, *ln1_b;

@@ -13,6 +13,7 @@ real checkpoint: **parity unpinned**.
 
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 
 import torch
@@ -171,13 +172,15 @@ def forward_features_bf16_storage(cfg: VitCfg, sd: dict, x: torch.Tensor) -> dic
         h = _bf(F.layer_norm(t, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], cfg.ln_eps))
         w = sd[p + "attn.qkv.weight"].clone()
         bias = sd[p + "attn.qkv.bias"].clone()
-        w[:C] *= hd**-0.5  # the engine folds the (power-of-two) scale into the q rows before rounding: exact
-        bias[:C] *= hd**-0.5
+        # the engine folds head_dim^-0.5 * log2(e) into the q rows before rounding them to bf16 and its attention kernel
+        # works in log2 units (exp2): same mathematics, these rounding points
+        w[:C] *= hd**-0.5 * math.log2(math.e)
+        bias[:C] *= hd**-0.5 * math.log2(math.e)
         qkv = _bf(F.linear(h, _bf(w), bias)).reshape(b, N, 3, nh, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         sc = q @ k.transpose(-2, -1)
         m = sc.amax(-1, keepdim=True)
-        e = torch.exp(sc - m)
+        e = torch.exp2(sc - m)
         a = (_bf(e) @ v) / e.sum(-1, keepdim=True)  # probabilities are rounded after exp(s - max), the sum stays fp32
         a = _bf(a.transpose(1, 2).reshape(b, N, C))
         t = t + sd[p + "ls1.gamma"] * F.linear(a, _bf(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])

@@ -86,9 +86,10 @@ def test_vit_s_outlier_channels_vs_oracle(gpu):
     [0.1, 5], q/k projections x2 each.  The fp32 oracle's pre-norm stream then peaks at ~150x its median.
     Two references: the fp32 oracle, and the oracle with exact arithmetic but the HIP path's bf16 STORAGE points
     (``forward_features_bf16_storage``).  Storage alone moves single outputs by ~0.55 here (measured: emulation vs fp32), so
-    the bound vs fp32 is "no worse than storage costs" (1.25x that + 0.05; mean <= 1e-2), and the kernels must stay close
-    to the storage emulation (measured on MI355X: max 0.17 / mean 0.0016 -- what remains is fp32 summation order and the
-    exp2 / erf approximations, amplified by the sharp softmax)."""
+    the bound vs fp32 is "no worse than storage costs" (on the mean; the maximum only has a ceiling), and the kernels must
+    stay close to the storage emulation (measured on MI355X: max 0.24 / mean 0.0022 -- what remains is fp32 summation order,
+    the deferred softmax maximum (P up to 2^3 before a row is re-anchored) and the exp2 / erf approximations, amplified by
+    the sharp softmax)."""
     from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine
     from oracle import dinov2 as o
     from oracle import preprocess as opre
@@ -117,9 +118,14 @@ def test_vit_s_outlier_channels_vs_oracle(gpu):
     got = eng.forward_features(x.to(gpu))["x_norm_patchtokens"].float().cpu()
     assert torch.isfinite(got).all()
     e_emu, e_f32 = (got - emu).abs(), (got - ref).abs()
-    stats = (float(e_emu.max()), float(e_emu.mean()), float(e_f32.max()), float(e_f32.mean()), float((emu - ref).abs().max()))
-    assert float(e_f32.max()) <= 1.25 * stats[4] + 5e-2 and float(e_f32.mean()) <= 1e-2, stats
-    assert float(e_emu.max()) <= 2.5e-1 and float(e_emu.mean()) <= 5e-3, stats
+    e_store = (emu - ref).abs()
+    stats = (float(e_emu.max()), float(e_emu.mean()), float(e_f32.max()), float(e_f32.mean()), float(e_store.max()), float(e_store.mean()))
+    # Single-element maxima are chaotic under this stress (sharp softmax behind a 150x outlier stream: the emulation's own
+    # maximum vs fp32 moved between 0.21 and 0.55 with nothing but the rounding point of the q scale), so the comparison with
+    # fp32 is on the MEAN (no worse than 1.5x what storage alone costs) plus an absolute ceiling on the maximum; closeness
+    # to the exact-arithmetic emulation of the same storage plan is the kernel-correctness bar.
+    assert float(e_f32.mean()) <= 1.5 * stats[5] + 1e-3 and float(e_f32.mean()) <= 1e-2 and float(e_f32.max()) <= 0.75, stats
+    assert float(e_emu.max()) <= 3e-1 and float(e_emu.mean()) <= 5e-3, stats
 
 
 def test_head_narrow_golden(gpu, gold):

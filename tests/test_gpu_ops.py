@@ -19,6 +19,9 @@ def hf(t):  # the segmentation head stores fp16 (11 significand bits: rel. 2^-12
     return t.to(torch.float16)
 
 
+LOG2E = 1.4426950408889634
+
+
 def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
 
@@ -208,15 +211,16 @@ def test_layernorm(gpu, C):
 @pytest.fixture
 def attn_variant(request):
     """All attention kernels kept in attention.hip are parity-tested: 0 = 32 query rows per wave (4-wave blocks),
-    3 = three K/V buffers, 4 / 5 = 64 query rows per wave in 3- / 4-wave blocks."""
+    3 = three K/V buffers, 4 / 5 = 64 query rows per wave in 3- / 4-wave blocks, 6 (default) = 0 with the running maximum
+    subtracted inside the QK^T product (augmented k-step) and raised only when a row outgrows it by 2^3."""
     from cryovit_amd import _lib
 
     _lib.set_option("attn_variant", request.param)
     yield request.param
-    _lib.set_option("attn_variant", 0)
+    _lib.set_option("attn_variant", 6)  # the default
 
 
-@pytest.mark.parametrize("attn_variant", [0, 3, 4, 5], indirect=True)
+@pytest.mark.parametrize("attn_variant", [0, 3, 4, 5, 6], indirect=True)
 @pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1)])
 def test_attention(gpu, nt, slices, heads, attn_variant):
     from cryovit_amd.engine import ops
@@ -228,14 +232,14 @@ def test_attention(gpu, nt, slices, heads, attn_variant):
     q = q * 1.5  # spread the logits so the online-softmax rescale path is exercised
     qk = torch.randn(ops.alloc_rows(M), 2 * C, generator=torch.Generator().manual_seed(27)).to(torch.bfloat16)  # junk pad
     qkv = qk[:M].reshape(slices, ntp, 2 * C)
-    qkv[:, :nt, :C] = bf(q * 0.125).reshape(slices, nt, C)
+    qkv[:, :nt, :C] = bf(q * 0.125 * LOG2E).reshape(slices, nt, C)  # the kernel takes Q in log2 units (header)
     qkv[:, :nt, C:] = bf(k).reshape(slices, nt, C)
     vt = torch.zeros(slices, heads, 64, kp, dtype=torch.bfloat16)
     vt[..., :nt] = bf(v).permute(0, 2, 3, 1)
     vt[..., nt:ntp] = 3.0  # finite garbage in the pad tokens must be masked out
     out = torch.zeros(ops.alloc_rows(M), C, dtype=torch.bfloat16, device=gpu)
     ops.attention(qk.to(gpu), vt.to(gpu), out, slices=slices, heads=heads, ntok=nt, ntp=ntp, kp=kp)
-    qf, kf, vf = bf(q * 0.125).float(), bf(k).float(), bf(v).float()
+    qf, kf, vf = bf(q * 0.125 * LOG2E).float() / LOG2E, bf(k).float(), bf(v).float()
     att = torch.softmax(torch.einsum("snhd,smhd->shnm", qf, kf), dim=-1)
     ref = torch.einsum("shnm,smhd->snhd", att, vf).reshape(slices, nt, C)
     got = out[:M].float().cpu().reshape(slices, ntp, C)
@@ -244,22 +248,27 @@ def test_attention(gpu, nt, slices, heads, attn_variant):
     assert torch.all(got[:, nt:] == 0), "padding rows must not be written"
 
 
-@pytest.mark.parametrize("attn_variant", [0, 4], indirect=True)
-def test_attention_forced_rescale(gpu, attn_variant):
-    """One key row spiked against one query so the running max jumps in a late tile (rare-branch test)."""
+@pytest.mark.parametrize("spike", [4.0, 60.0, -60.0])
+@pytest.mark.parametrize("attn_variant", [0, 4, 6], indirect=True)
+def test_attention_forced_rescale(gpu, attn_variant, spike):
+    """One key row spiked against one query so the running max jumps in a late tile (rare-branch test).  spike 60: the jump
+    is far above the deferred-maximum threshold of variant 6 (its raise-and-rescale branch); spike -60 with the shift below:
+    every score of the tomogram is far below zero (rows must be anchored at their own maximum, not at 0)."""
     from cryovit_amd.engine import ops
 
     nt, slices, heads, C = 200, 1, 1, 64
     ntp, kp = ops.round_up(nt, 8), ops.round_up(nt, 64)
     q, k, v = rnd(1, nt, 1, 64, seed=28), rnd(1, nt, 1, 64, seed=29), rnd(1, nt, 1, 64, seed=30)
-    k[0, 150, 0] = q[0, 7, 0] * 4.0
+    if spike < 0:  # all logits ~ -300 (natural units): q . k = -8 * 300 / 0.125 ... through one shared coordinate
+        q[0, :, 0, 1], k[0, :, 0, 1] = 50.0, -48.0
+    k[0, 150, 0] = q[0, 7, 0] * abs(spike)
     qk = torch.zeros(ops.alloc_rows(ntp), 2 * C, dtype=torch.bfloat16)
-    qk[:nt, :C], qk[:nt, C:] = bf(q * 0.125).reshape(nt, C), bf(k).reshape(nt, C)
+    qk[:nt, :C], qk[:nt, C:] = bf(q * 0.125 * LOG2E).reshape(nt, C), bf(k).reshape(nt, C)
     vt = torch.zeros(1, 1, 64, kp, dtype=torch.bfloat16)
     vt[0, 0, :, :nt] = bf(v).reshape(nt, 64).T
     out = torch.zeros(ops.alloc_rows(ntp), C, dtype=torch.bfloat16, device=gpu)
     ops.attention(qk.to(gpu), vt.to(gpu), out, slices=1, heads=1, ntok=nt, ntp=ntp, kp=kp)
-    qf, kf, vf = bf(q * 0.125).float().reshape(nt, 64), bf(k).float().reshape(nt, 64), bf(v).float().reshape(nt, 64)
+    qf, kf, vf = bf(q * 0.125 * LOG2E).float().reshape(nt, 64) / LOG2E, bf(k).float().reshape(nt, 64), bf(v).float().reshape(nt, 64)
     ref = torch.softmax(qf @ kf.T, -1) @ vf
     got = out[:nt].float().cpu()
     assert torch.allclose(got, ref, atol=2e-2, rtol=2e-2), float((got - ref).abs().max())
