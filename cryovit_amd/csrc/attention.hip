@@ -59,9 +59,15 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     const bool wave_idle = VARIANT != 1 && q0 >= ntok;  // (variant 1 keeps the old behaviour for A/B runs)
 
     // Q fragments: B operand of S^T = K Q^T.  lane (r,h) holds Q[q0+r][16*ks + 8*h + j]
+    // The loads are inline asm with their own wait (below, before the key loop): left to hipcc, the waits for these four
+    // loads land at their first use INSIDE the loop as vmcnt(3)..vmcnt(0) -- and since the LDS-DMA of the loop is issued
+    // from asm (invisible to hipcc's counters), that vmcnt(0) drained the tile prefetch it had just issued, every tile.
     bf16x8 qf[4];
+    {
+        const uint16_t* qsrc = Qp + (long)qrow * ldqk + 8 * h;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Qp + (long)qrow * ldqk + 16 * ks + 8 * h);
+        for (int ks = 0; ks < 4; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[ks]) : "v"(qsrc + 16 * ks) : "memory");
+    }
     // Scores arrive in LOG2 units: the caller folds head_dim^-0.5 * log2(e) into the Q projection (one rounding, at weight
     // packing), so p = exp2(S - m) with no multiply.
     // VARIANT 6: the running maximum is subtracted INSIDE the matrix product: a fifth
@@ -113,6 +119,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     constexpr bool ABL_NOSYNC = VARIANT == 11 || VARIANT == 12, ABL_NODMA = VARIANT == 11 || VARIANT == 13;
     issue(0, 0);
     if (NBUF == 3 && nkv > 1) issue(1, 1);
+    // Q has landed (and tile 0 / 1 with it: the loop's own first wait is then a no-op); "+v" pins every use of qf below this
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
     int buf = 0;  // buffer of tile j
     for (int j = 0; j < nkv; ++j) {
         if (!ABL_NOSYNC || j == 0) {
