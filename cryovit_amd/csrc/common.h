@@ -23,8 +23,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(uint16_t, b);
 }
+// two floats -> one dword of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32.  (Written as two scalar casts OR-ed together,
+// hipcc still converts pairwise but then re-packs with v_and / v_lshl / v_or_sdwa: three more VALU instructions per dword --
+// half of the bf16 GEMM epilogue's vector instructions.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 // fp16 storage (the segmentation head: the reference runs it under fp16 autocast, configs `precision: "16-mixed"`).
 // Conversions saturate at the largest finite half instead of producing inf.

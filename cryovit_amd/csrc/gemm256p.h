@@ -313,13 +313,15 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                     const f32x4 a = acc[f][u];
                     *(float4*)(stg + (lane & 15) * PITCH + 16 * gq + 4 * f) = float4{a[0], a[1], a[2], a[3]};
                 }
+                float4 d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i] = *(const float4*)(stg + (4 * i + mrow) * PITCH + ncol);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 d = *(const float4*)(stg + (4 * i + mrow) * PITCH + ncol);
                     const float4 xq4 = xv[u % 3][i];
                     if (FULL || (16 * u + 4 * i + mrow < mleft && nok)) {
                         float4 o;
-                        o.x = xq4.x + d.x; o.y = xq4.y + d.y; o.z = xq4.z + d.z; o.w = xq4.w + d.w;
+                        o.x = xq4.x + d[i].x; o.y = xq4.y + d[i].y; o.z = xq4.z + d[i].z; o.w = xq4.w + d[i].w;
                         gst16_saddr_nt(xu, loff[i], __builtin_bit_cast(u32x4, o));
                     }
                 }
@@ -377,13 +379,17 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                         *(uint4*)dst = uint4{w[0], w[1], w[2], w[3]};
                     }
                 }
+                // (all the staged rows are read BEFORE the first store: the asm stores are ordering points for hipcc, and read /
+                //  wait / store one row at a time exposed the LDS latency 16 times per tile)
+                uint4 d[32 / RPI];
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i) d[i] = *(const uint4*)(stg + (RPI * i + srow) * PITCHB + spiece * 16);
 #pragma unroll
                 for (int i = 0; i < 32 / RPI; ++i) {
                     const int row = RPI * i + srow;
-                    const uint4 d = *(const uint4*)(stg + row * PITCHB + spiece * 16);
                     if (FULL || (32 * q + row < mleft && ook)) {
-                        if constexpr (O16 == 16) gst16_saddr_nt(oq, loff[i], u32x4{d.x, d.y, d.z, d.w});
-                        else gst16_saddr(oq, loff[i], u32x4{d.x, d.y, d.z, d.w});  // 64-B segments: left to the L2's write combining
+                        if constexpr (O16 == 16) gst16_saddr_nt(oq, loff[i], u32x4{d[i].x, d[i].y, d[i].z, d[i].w});
+                        else gst16_saddr(oq, loff[i], u32x4{d[i].x, d[i].y, d[i].z, d[i].w});  // 64-B segments: left to the L2's write combining
                     }
                 }
             }
