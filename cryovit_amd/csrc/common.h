@@ -108,6 +108,8 @@ __device__ __forceinline__ float4 ld_stream(const float* p) {
     const f32x4 v = g_stream_io ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p;
     return float4{v[0], v[1], v[2], v[3]};
 }
+// 16 B of 16-bit data, plain cache policy (tensors a following kernel reads again: the Infinity Cache may still hold them)
+__device__ __forceinline__ uint4 ld_stream16(const uint16_t* p) { return *(const uint4*)p; }
 __device__ __forceinline__ void st_stream(float* p, const float4& v) {
     const f32x4 t{v.x, v.y, v.z, v.w};
     if (g_stream_io) __builtin_nontemporal_store(t, (f32x4*)p); else *(f32x4*)p = t;

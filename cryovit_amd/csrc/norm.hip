@@ -253,8 +253,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
     const long v0 = (long)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
-    for (long v = v0 + vsub; v < v1; v += vstride) {
-        const uint4 u = *(const uint4*)(x + v * C + cc * 8);
+    auto add = [&](const uint4& u) {
         const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -262,7 +261,17 @@ __global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x
             s[2 * e] += a; q[2 * e] += a * a;
             s[2 * e + 1] += b; q[2 * e + 1] += b * b;
         }
+    };
+    // four 16-B loads in flight per thread (a block covers 64+ voxels: enough blocks to fill the chip even at C = 1024);
+    // the order in which a thread adds its voxels is the same with and without the unrolling
+    const uint16_t* xp = x + cc * 8;
+    long v = v0 + vsub;
+    for (; v + 3 * vstride < v1; v += 4 * vstride) {
+        const uint4 u0 = ld_stream16(xp + v * C), u1 = ld_stream16(xp + (v + vstride) * C);
+        const uint4 u2 = ld_stream16(xp + (v + 2 * vstride) * C), u3 = ld_stream16(xp + (v + 3 * vstride) * C);
+        add(u0); add(u1); add(u2); add(u3);
     }
+    for (; v < v1; v += vstride) add(ld_stream16(xp + v * C));
 #pragma unroll
     for (int e = 0; e < 8; ++e) { part[tid][e] = s[e]; part[tid][8 + e] = q[e]; }
     __syncthreads();
@@ -282,46 +291,68 @@ __global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x
     }
 }
 
-// stats[k] = sum over blocks of partials[b][k], k < 2G: one 64-lane group per statistic, fixed order, double accumulation
-__global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ partials, int nblk, int G2, float* __restrict__ stats) {
-    const int k = blockIdx.x, lane = threadIdx.x;
-    double acc = 0.0;
-    for (int b = lane; b < nblk; b += 64) acc += (double)partials[(long)b * G2 + k];
+// One 64-lane group per GROUP: stats[g] / stats[G + g] = the block partials added in a fixed order (double accumulation), then
+// the per-channel affine form of the normalisation, coef[c] = rstd * w[c], coef[C + c] = b[c] - mean * coef[c]  (fp64 statistics,
+// one rounding to fp32 each: the arithmetic k_gn_apply used to repeat in every block)
+__global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ partials, int nblk, int G, float* __restrict__ stats,
+                                                    const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ coef,
+                                                    long nvox, int C, float eps) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int k = lane; k < nblk; k += 64) {
+        s += (double)partials[(long)k * 2 * G + g];
+        q += (double)partials[(long)k * 2 * G + G + g];
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) stats[k] = (float)acc;
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    s = (double)(float)s; q = (double)(float)q;  // (the statistics are published, and used, as fp32 sums)
+    if (lane == 0) { stats[g] = (float)s; stats[G + g] = (float)q; }
+    const int cpg = C / G;
+    const double cnt = (double)nvox * cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int e = lane; e < cpg; e += 64) {
+        const int c = g * cpg + e;
+        const float sc = rstd * w[c];
+        coef[c] = sc;
+        coef[C + c] = b[c] - (float)mean * sc;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x, const float* __restrict__ stats,
-                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                  uint16_t* __restrict__ out, long nvox, int C, int G, float eps,
-                                                  long vox_per_block) {
+__global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x, const float* __restrict__ coef,
+                                                  uint16_t* __restrict__ out, long nvox, int C, long vox_per_block) {
     const int tid = threadIdx.x;
     const int cpt = C >> 3;
     const int cc = tid % cpt, vsub = tid / cpt, vstride = 256 / cpt;
-    const int cpg = C / G;
-    const double cnt = (double)nvox * cpg;
     float sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int c = cc * 8 + e, g = c / cpg;
-        const double mean = (double)stats[g] / cnt;
-        double var = (double)stats[G + g] / cnt - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        sc[e] = rstd * w[c];
-        sh[e] = b[c] - (float)mean * sc[e];
+    {
+        const float4 a0 = *(const float4*)(coef + cc * 8), a1 = *(const float4*)(coef + cc * 8 + 4);
+        const float4 b0 = *(const float4*)(coef + C + cc * 8), b1 = *(const float4*)(coef + C + cc * 8 + 4);
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
     }
-    const long v0 = (long)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
-    for (long v = v0 + vsub; v < v1; v += vstride) {
-        const uint4 u = *(const uint4*)(x + v * C + cc * 8);
+    auto norm = [&](const uint4& u) {
         uint4 o;
         o.x = pack2h(fmaf(hlo(u.x), sc[0], sh[0]), fmaf(hhi(u.x), sc[1], sh[1]));
         o.y = pack2h(fmaf(hlo(u.y), sc[2], sh[2]), fmaf(hhi(u.y), sc[3], sh[3]));
         o.z = pack2h(fmaf(hlo(u.z), sc[4], sh[4]), fmaf(hhi(u.z), sc[5], sh[5]));
         o.w = pack2h(fmaf(hlo(u.w), sc[6], sh[6]), fmaf(hhi(u.w), sc[7], sh[7]));
-        *(uint4*)(out + v * C + cc * 8) = o;
+        return o;
+    };
+    const long v0 = (long)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+    const long co = cc * 8;
+    long v = v0 + vsub;
+    for (; v + 3 * vstride < v1; v += 4 * vstride) {
+        const uint4 u0 = ld_stream16(x + v * C + co), u1 = ld_stream16(x + (v + vstride) * C + co);
+        const uint4 u2 = ld_stream16(x + (v + 2 * vstride) * C + co), u3 = ld_stream16(x + (v + 3 * vstride) * C + co);
+        *(uint4*)(out + v * C + co) = norm(u0);
+        *(uint4*)(out + (v + vstride) * C + co) = norm(u1);
+        *(uint4*)(out + (v + 2 * vstride) * C + co) = norm(u2);
+        *(uint4*)(out + (v + 3 * vstride) * C + co) = norm(u3);
     }
+    for (; v < v1; v += vstride) *(uint4*)(out + v * C + co) = norm(ld_stream16(x + v * C + co));
 }
 
 }  // namespace cvx
@@ -367,21 +398,24 @@ extern "C" int cvx_groupnorm_f16(const void* x, const float* w, const float* b, 
     const int cpt = C / 8;
     if (C % 8 || cpt > 256 || (cpt & (cpt - 1)) || C % G || G > 128)
         return cvx_fail("groupnorm: C must be 8*2^k <= 2048, divisible by G, G <= 128");
-    // stats[0 .. 2G) = the sums; stats[2G ...) = per-block partials of at most CVX_GN_BLOCKS blocks
-    long nstat = (nvox + 2047) / 2048;
-    if (nstat > CVX_GN_BLOCKS) nstat = CVX_GN_BLOCKS;
-    const long vpb_stat = (nvox + nstat - 1) / nstat;
+    // stats[0 .. 2G) = the sums; then per-block partials of nstat blocks; the per-channel coefficients (2C floats = C/G more
+    // "blocks") behind them: 2G * (1 + CVX_GN_BLOCKS) floats in all
+    const int vstride = 256 / cpt;
+    long vpb_stat = std::max<long>(64, 8L * vstride);           // >= 8 voxels per thread
+    long nstat = (nvox + vpb_stat - 1) / vpb_stat;
+    const long cap = CVX_GN_BLOCKS - C / G;
+    if (nstat > cap) { nstat = cap; vpb_stat = (nvox + nstat - 1) / nstat; nstat = (nvox + vpb_stat - 1) / vpb_stat; }
     float* partials = stats + 2 * G;
+    float* coef = partials + nstat * 2 * G;
     hipLaunchKernelGGL(k_gn_stats, dim3((unsigned)nstat), dim3(256), sizeof(float) * 2 * C, st, (const uint16_t*)x, partials, nvox, C, G,
                        vpb_stat);
     int rc = cvx_check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gn_finalize, dim3(2 * G), dim3(64), 0, st, partials, (int)nstat, 2 * G, stats);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(G), dim3(64), 0, st, partials, (int)nstat, G, stats, w, b, coef, nvox, C, eps);
     rc = cvx_check_launch();
     if (rc) return rc;
-    const long vox_per_block = 2048;
+    const long vox_per_block = 8L * vstride;                     // 8 voxels per thread, four 16-B loads in flight
     const unsigned nblk = (unsigned)((nvox + vox_per_block - 1) / vox_per_block);
-    hipLaunchKernelGGL(k_gn_apply, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, stats, w, b, (uint16_t*)out, nvox, C, G,
-                       eps, vox_per_block);
+    hipLaunchKernelGGL(k_gn_apply, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, nvox, C, vox_per_block);
     return cvx_check_launch();
 }

@@ -151,8 +151,9 @@ int cvx_features_to_channels_last(const void* feats_f16, void* out_cl, int C, lo
 
 /* GroupNorm over a channels-last fp16 volume x[nvox][C], G groups (<= 128), biased variance, eps inside sqrt
  * (nn.GroupNorm(G, C, eps=1e-3) -- cryovit.py:69).  Three launches: per-block partial sums, fixed-order reduction (no
- * atomics: results are bitwise reproducible), apply -> fp16 out.  stats: fp32 scratch of 2*G*(1 + CVX_GN_BLOCKS) floats
- * (stats[0..2G) = sum | sum of squares per group after the call). */
+ * atomics: results are bitwise reproducible) that also leaves the per-channel affine coefficients, apply -> fp16 out.
+ * stats: fp32 scratch of 2*G*(1 + CVX_GN_BLOCKS) floats (stats[0..2G) = sum | sum of squares per group after the call;
+ * block partials and the 2*C coefficients behind them). */
 #define CVX_GN_BLOCKS 1024
 int cvx_groupnorm_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
                        int G, float eps, hipStream_t stream);

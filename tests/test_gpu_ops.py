@@ -521,6 +521,30 @@ def test_gemm256_bf16_and_resid(gpu, M, N, K, gemm256_variant):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize("gemm256_variant", [(1, 5), (1, 9)], indirect=True)
+def test_gemm256_padded_columns(gpu, gemm256_variant):
+    """N not a multiple of the tile: W / bias / gamma padded to 512 rows, 400 valid output columns, the output buffers exactly
+    400 (bf16) / 400 (fp32) wide -- the 256-tile kernels must not touch a column >= N (a stray store would land in the next
+    row), in the persistent kernel's predicated edge variant and in the one-shot kernel; 9 x 2 tiles, M not a tile multiple."""
+    from cryovit_amd._lib import EPI_BF16, EPI_RESID
+    from cryovit_amd.engine import ops
+
+    M, N, NP, K = 2100, 400, 512, 320
+    a, w, b, gm = rnd(M, K, seed=91), rnd(N, K, seed=92, scale=K**-0.5), rnd(N, seed=93), rnd(N, seed=94)
+    A, Wd = padded_bf16(a, ops.alloc_rows(M), K, gpu), padded_bf16(w, NP, K, gpu)
+    ref = bf(a).float() @ bf(w).float().T + b
+    out = torch.full((ops.alloc_rows(M), N), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_BF16, A, Wd, out, padded_f32(b, NP, gpu), m=M, n=N)
+    assert torch.allclose(out[:M].float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    assert torch.all(out[M:].float() == 7.0)
+    x0 = rnd(M, N, seed=95)
+    x = torch.full((ops.alloc_rows(M), N), 3.0, device=gpu)
+    x[:M] = x0.to(gpu)
+    ops.gemm(EPI_RESID, A, Wd, x, padded_f32(b, NP, gpu), m=M, n=N, gamma=padded_f32(gm, NP, gpu))
+    assert torch.allclose(x[:M].cpu(), x0 + gm * ref, atol=2e-4, rtol=1e-4)
+    assert torch.all(x[M:] == 3.0)
+
+
 @pytest.mark.parametrize("gemm256_variant", [(1, 5), (1, 9), (2, 0)], indirect=True)
 def test_gemm256_swiglu_vt_patch(gpu, gemm256_variant):
     from cryovit_amd._lib import EPI_PATCH, EPI_SWIGLU, EPI_VT

@@ -1,0 +1,11 @@
+set -e -o pipefail
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "groupnorm or padded_columns" > gpurun_out/s2_gn_tests.log 2>&1 || { tail -30 gpurun_out/s2_gn_tests.log; exit 1; }
+tail -3 gpurun_out/s2_gn_tests.log
+python -m pytest tests/test_gpu_model.py tests/test_gpu_pipeline.py -x -q -m gpu > gpurun_out/s2_model_tests.log 2>&1 || { tail -30 gpurun_out/s2_model_tests.log; exit 1; }
+tail -3 gpurun_out/s2_model_tests.log
+python tools/bench_head.py 10 | tee gpurun_out/s2_head_a.log
+export TMPDIR=/tmp
+R=$PWD
+cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_head -o head -- python3 $R/tools/bench_head.py 5 > $R/gpurun_out/prof_head.log 2>&1
+cd $R && python tools/bench_head.py --summarize gpurun_out/prof_head | tee gpurun_out/s2_head_launches_a.txt
