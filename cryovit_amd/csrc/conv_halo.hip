@@ -138,6 +138,216 @@ static int launch_halo(const cvx_conv3d_desc& d, hipStream_t st) {
     return cvx_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Z-MARCHING form (round 2).  The tile kernel above stages all three planes of every tile from scratch, synchronously: a
+// 4.6x read amplification out of the L2 and no overlap inside a workgroup.  Here a workgroup owns one 4 x 64-voxel COLUMN and
+// one residue class of z (z = r, r + dil, r + 2 dil, ...: along that sequence a (dil,1,1)-dilated stencil is a plain 3-plane
+// stencil), keeps the planes z - dil, z, z + dil in an LDS ring of four slots and fetches ONE new plane per step by LDS-DMA
+// while the current step computes: 1.55x instead of 4.6x L2 reads per voxel, one barrier per step, the fetch a whole step ahead.
+// Out-of-volume voxels (the "same" padding) are fetched from the zero page, like every other voxel: no special cases in the
+// ring.  C_out up to 32 (NF = 2 weight fragments): SynthesisBlock 3's 32 -> 32 convolutions run here too.  With C_out <= 8 only
+// lane groups 0 and 1 of the accumulator layout carry channels: fragments 2 / 3 move to lanes 32-63 (v_permlane32_swap) so all
+// 64 lanes evaluate GELUs (the epilogue, not the MFMAs, is the larger part of the 8-channel layer).
+// ---------------------------------------------------------------------------------------------------
+template <int CIN, int NF>
+struct MarchCfg {
+    static constexpr int K = 27 * CIN;
+    static constexpr int KSTEPS = (K + 31) / 32;
+    static constexpr int WPITCH = KSTEPS * 32 + 8;
+    static constexpr int PV = CIN / 8;                                  // 16-B pieces per voxel
+    static constexpr int NP = CH_HY * CH_HX * PV;                       // pieces per plane
+    static constexpr int NWI = (NP + 63) / 64;                          // wave-instructions per plane (1 KiB each)
+    static constexpr int NQ = (NWI + 3) / 4;                            // ... per wave
+    static constexpr int SLOT_BYTES = NWI * 1024;
+    static constexpr int W_BYTES = 16 * NF * WPITCH * 2;
+    static constexpr int LDS_BYTES = 4 * SLOT_BYTES + W_BYTES;
+};
+
+template <int CIN, int NF, int ACT>
+__global__ __launch_bounds__(256) void k_conv3_march(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt /*[16 NF][ldw]*/,
+                                                     long ldw, const float* __restrict__ bias, const void* __restrict__ zero_page,
+                                                     uint16_t* __restrict__ out, int cout, int D, int H, int W, int dil, int tiles_x,
+                                                     int tiles_y, int nitems) {
+    using Cfg = MarchCfg<CIN, NF>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                             // 4 x [CH_HY][CH_HX][CIN] fp16 (+ the last wave-instruction's tail)
+    uint16_t* wl = (uint16_t*)(smem + 4 * Cfg::SLOT_BYTES);        // [16 NF][WPITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+
+    for (int i = tid; i < 16 * NF * (Cfg::KSTEPS * 4); i += 256) {
+        const int n = i / (Cfg::KSTEPS * 4), c8 = i % (Cfg::KSTEPS * 4);
+        uint4 u = uint4{0u, 0u, 0u, 0u};
+        if (c8 * 8 < Cfg::K) u = *(const uint4*)(wt + (long)n * ldw + c8 * 8);
+        *(uint4*)(wl + n * Cfg::WPITCH + c8 * 8) = u;
+    }
+    const bool swap8 = cout <= 8;           // (uniform) fragments 2 / 3 are finished by lanes 32-63
+    const int ge = swap8 ? (g & 1) : g;     // lane group whose channels this lane finishes
+    float bv[NF][4];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[nf][i] = bias[16 * nf + 4 * ge + i];
+
+    // k-step s, lane group g covers k = 32 s + 8 g .. +7 -> tap = k / CIN: plane kz of the ring + an in-plane byte offset
+    int foff[Cfg::KSTEPS], fkz[Cfg::KSTEPS];
+#pragma unroll
+    for (int s = 0; s < Cfg::KSTEPS; ++s) {
+        const int k = 32 * s + 8 * g;
+        int tap = k / CIN;
+        const int c0 = k - tap * CIN;
+        tap = tap < 27 ? tap : 26;  // padded k: zero weights
+        const int kz = tap / 9, r9 = tap - kz * 9, ky = r9 / 3, kx = r9 - ky * 3;
+        fkz[s] = kz;
+        foff[s] = (((wave + ky) * CH_HX + li + kx) * CIN + c0) * 2;
+    }
+    const char* zp = (const char*)zero_page;
+    __syncthreads();
+
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int r = item % dil, col = item / dil;
+        const int tx = col % tiles_x, ty = col / tiles_x;
+        const int x0 = tx * CH_TX - 1, y0 = ty * CH_TY - 1;
+        const int J = (D - r + dil - 1) / dil;  // z_j = r + j dil, j < J
+        // this lane's pieces of a plane: wave-instruction q*4 + wave, piece index i -> (voxel, 16-B part)
+        uint32_t poff[Cfg::NQ];
+        uint32_t pvalid = 0;
+#pragma unroll
+        for (int q = 0; q < Cfg::NQ; ++q) {
+            const int i = (q * 4 + wave) * 64 + lane;
+            const int vox = i / Cfg::PV, p = i - vox * Cfg::PV;
+            const int hy = vox / CH_HX, hx = vox - hy * CH_HX;
+            const int xx = x0 + hx, yy = y0 + hy;
+            const bool ok = i < Cfg::NP && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
+            poff[q] = ok ? (uint32_t)(((yy * W + xx) * CIN + p * 8) * 2) : 0u;
+            pvalid |= ok ? (1u << q) : 0u;
+        }
+        auto fetch = [&](int jp) {  // plane index jp (z = r + jp dil; -1 and J are padding planes) -> ring slot (jp + 1) & 3
+            const int zz = r + jp * dil;
+            const bool zok = jp >= 0 && zz < D;
+            const char* base = (const char*)(in + (long)(zok ? zz : 0) * H * W * CIN);
+            const uint32_t dst = lds_addr(ring) + (uint32_t)((jp + 1) & 3) * Cfg::SLOT_BYTES;
+#pragma unroll
+            for (int q = 0; q < Cfg::NQ; ++q) {
+                if ((q * 4 + wave) >= Cfg::NWI) break;  // (uniform)
+                const char* src = (zok && (pvalid >> q & 1)) ? base + poff[q] : zp;
+                glds16_vaddr(src, dst + (uint32_t)(q * 4 + wave) * 1024u);
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the previous column's last fragment reads are done
+        fetch(-1);
+        fetch(0);
+        fetch(1);
+        const int y = ty * CH_TY + wave;
+        for (int j = 0; j < J; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // planes j-1, j, j+1 have landed (and step j-1's stores retired)
+            __builtin_amdgcn_s_barrier();                     // ... for every wave; step j-1's reads of slot (j+3)&3 are done
+            if (j + 2 <= J) fetch(j + 2);
+            f32x4 acc[NF][4];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) acc[nf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < Cfg::KSTEPS; ++s) {
+                const char* pl = ring + ((j + fkz[s]) & 3) * Cfg::SLOT_BYTES + foff[s];
+                bf16x8 wf[NF];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) wf[nf] = *(const bf16x8*)(wl + (16 * nf + li) * Cfg::WPITCH + 32 * s + 8 * g);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const bf16x8 xf = *(const bf16x8*)(pl + 16 * f * CIN * 2);
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) acc[nf][f] = mfma16x16x32<true>(wf[nf], xf, acc[nf][f]);
+                }
+            }
+            const int z = r + j * dil;
+            uint16_t* orow = out + ((long)z * H + y) * W * cout;
+            if (swap8) {
+                // lanes 32-63 (groups 2, 3: padding rows of the 16-row weight fragment) take fragments 2 / 3 of lanes 0-31
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][0][i]), __float_as_uint(acc[0][2][i]), false, false);
+                    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0][1][i]), __float_as_uint(acc[0][3][i]), false, false);
+                    acc[0][0][i] = __uint_as_float(a[0]);
+                    acc[0][1][i] = __uint_as_float(b[0]);
+                }
+                if (y < H && 4 * ge < cout) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int x = tx * CH_TX + 16 * (f + 2 * (lane >> 5)) + li;
+                        if (x >= W) continue;
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float t = acc[0][f][i] + bv[0][i];
+                            v[i] = ACT == 1 ? gelu_erf(t) : t;
+                        }
+                        *(uint2*)(orow + (long)x * cout + 4 * ge) = uint2{pack2h(v[0], v[1]), pack2h(v[2], v[3])};
+                    }
+                }
+            } else if (y < H) {
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    if (16 * nf + 4 * g >= cout) continue;
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int x = tx * CH_TX + 16 * f + li;
+                        if (x >= W) continue;
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float t = acc[nf][f][i] + bv[nf][i];
+                            v[i] = ACT == 1 ? gelu_erf(t) : t;
+                        }
+                        *(uint2*)(orow + (long)x * cout + 16 * nf + 4 * g) = uint2{pack2h(v[0], v[1]), pack2h(v[2], v[3])};
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA may be in flight when the workgroup releases its LDS)
+}
+
+template <int CIN, int NF>
+static int launch_march(const cvx_conv3d_desc& d, hipStream_t st) {
+    using Cfg = MarchCfg<CIN, NF>;
+    static_assert(Cfg::LDS_BYTES <= 160 * 1024, "ring + weights must fit the CU's LDS");
+    const int tiles_x = (d.W + CH_TX - 1) / CH_TX, tiles_y = (d.H + CH_TY - 1) / CH_TY;
+    const int dil = d.dil < d.D ? d.dil : d.D;  // (dil >= D: every z is its own sequence of one plane; the neighbours are padding)
+    const long nitems = (long)tiles_x * tiles_y * dil;
+    if (nitems > 0x7fffffffL) return cvx_fail("conv3d: volume too large for the marching kernel");
+    const int per_cu = (160 * 1024) / Cfg::LDS_BYTES;
+    const long want = 256L * (per_cu > 8 ? 8 : per_cu);
+    const unsigned nblk = (unsigned)(nitems < want ? nitems : want);
+    auto k = d.act ? k_conv3_march<CIN, NF, 1> : k_conv3_march<CIN, NF, 0>;
+    CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(256), Cfg::LDS_BYTES, st, (const uint16_t*)d.in, (const uint16_t*)d.w, (long)d.k_pad, d.bias,
+                       d.zero_page, (uint16_t*)d.out, d.cout, d.D, d.H, d.W, dil, tiles_x, tiles_y, (int)nitems);
+    return cvx_check_launch();
+}
+
+bool conv3_march_eligible(const cvx_conv3d_desc& d) {
+    return (d.n_pad == 16 || d.n_pad == 32) && d.cout % 4 == 0 && d.cout <= d.n_pad && (d.C == 8 || d.C == 16 || d.C == 32) &&
+           d.k_pad >= 27 * d.C && d.zero_page != nullptr && (long)d.H * d.W * d.C * 2 < (1L << 31);
+}
+int conv3_march_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
+    if (d.n_pad == 32) {
+        switch (d.C) {
+            case 8: return launch_march<8, 2>(d, st);
+            case 16: return launch_march<16, 2>(d, st);
+            default: return launch_march<32, 2>(d, st);
+        }
+    }
+    switch (d.C) {
+        case 8: return launch_march<8, 1>(d, st);
+        case 16: return launch_march<16, 1>(d, st);
+        default: return launch_march<32, 1>(d, st);
+    }
+}
+
 // used by cvx_conv3d_f16 (gemm.hip) for the shapes this kernel is built for
 bool conv3_halo_eligible(const cvx_conv3d_desc& d) {
     return d.n_pad == 16 && d.cout % 4 == 0 && d.cout <= 16 && (d.C == 8 || d.C == 16 || d.C == 32) && d.k_pad >= 27 * d.C;

@@ -531,7 +531,8 @@ extern "C" int cvx_debug_read_gemm256p(unsigned long long* out96) {
     return 0;
 }
 
-static std::atomic<int> g_conv_halo{1};  // cvx_set_option("conv_halo", 0) forces the implicit-GEMM kernel (A/B runs, tests)
+// few-channel 3x3x3 convolutions: 2 = z-marching LDS-ring kernel (default), 1 = per-tile halo kernel, 0 = implicit GEMM (A/B runs, tests)
+static std::atomic<int> g_conv_halo{2};
 
 extern "C" int cvx_set_option(const char* name, int value) {
     if (!name) return cvx_fail("set_option: null name");
@@ -555,7 +556,10 @@ extern "C" int cvx_set_option(const char* name, int value) {
         g_gemm_stagger = value;  // persistent kernel: start offset between XCDs, cycles; the one-shot kernels: on / off
     }
     else if (!strcmp(name, "gemm_tail_split")) g_tail_split = value != 0;
-    else if (!strcmp(name, "conv_halo")) g_conv_halo = value != 0;
+    else if (!strcmp(name, "conv_halo")) {
+        if (!one_of({0, 1, 2})) return cvx_fail("set_option: conv_halo is 0 (implicit GEMM), 1 (tile halo) or 2 (z-marching ring)");
+        g_conv_halo = value;
+    }
     else if (!strcmp(name, "attn_variant")) {
         if (!one_of({0, 1, 3, 4, 5, 6}) && !(abl && one_of({10, 11, 12, 13})))
             return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");
@@ -698,6 +702,8 @@ static int conv3_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
 namespace cvx {  // conv_halo.hip: LDS-halo kernel for the full-resolution few-channel layers
 bool conv3_halo_eligible(const cvx_conv3d_desc& d);
 int conv3_halo_dispatch(const cvx_conv3d_desc& d, hipStream_t st);
+bool conv3_march_eligible(const cvx_conv3d_desc& d);
+int conv3_march_dispatch(const cvx_conv3d_desc& d, hipStream_t st);
 }
 
 extern "C" int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t st) {
@@ -705,6 +711,8 @@ extern "C" int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t st) {
     if (d->C % 8) return cvx_fail("conv3d: C_in must be a multiple of 8");
     if (d->k_pad % BK || d->k_pad < 27 * d->C) return cvx_fail("conv3d: K must be 27*C_in padded to a multiple of 64");
     if (d->cout % 4) return cvx_fail("conv3d: C_out must be a multiple of 4");
-    if (g_conv_halo && conv3_halo_eligible(*d)) return conv3_halo_dispatch(*d, st);
+    const int halo = g_conv_halo;
+    if (halo == 2 && conv3_march_eligible(*d)) return conv3_march_dispatch(*d, st);
+    if (halo && conv3_halo_eligible(*d)) return conv3_halo_dispatch(*d, st);
     return d->act ? conv3_dispatch<1>(*d, st) : conv3_dispatch<0>(*d, st);
 }

@@ -386,11 +386,15 @@ def test_conv3d(gpu, Cin, Cout, dil, D, H, W):
 
 
 @pytest.mark.parametrize("Cin,Cout,dil,D,H,W", [(32, 16, 2, 7, 9, 70), (16, 16, 1, 5, 12, 131), (8, 8, 1, 4, 7, 66), (16, 8, 3, 6, 4, 64),
-                                               (32, 12, 1, 3, 5, 33)])
+                                               (32, 12, 1, 3, 5, 33), (32, 32, 8, 19, 6, 40), (32, 32, 4, 9, 10, 65), (8, 4, 1, 1, 3, 5),
+                                               (16, 32, 5, 4, 5, 17), (8, 8, 2, 11, 13, 129)])
 def test_conv3d_halo_kernel(gpu, Cin, Cout, dil, D, H, W):
-    """The LDS-halo kernel of the full-resolution few-channel layers (C_in 8/16/32, C_out <= 16): ragged tiles in x and y,
-    dilation in z reaching outside the volume, C_out 8 / 12 / 16 -- against torch, and against the implicit-GEMM kernel the
-    same call uses when the option is off (same fp16 operands, fp32 accumulation in a different order)."""
+    """The LDS kernels of the few-channel layers (C_in 8/16/32): the z-marching ring kernel (option 2: C_out <= 32, one residue
+    class of z per workgroup, one new plane per step by LDS-DMA) and the per-tile halo kernel (option 1: C_out <= 16) --
+    ragged tiles in x and y, dilation in z reaching outside the volume (also dil >= D: every tap but the centre plane is
+    padding), D not a multiple of the dilation, C_out 4 / 8 (fragments finished by the upper lanes) / 12 / 16 / 32 -- against
+    torch, and against the implicit-GEMM kernel the same call uses when the option is off (same fp16 operands, fp32
+    accumulation in a different order)."""
     from cryovit_amd import _lib
     from cryovit_amd.engine import ops
     from cryovit_amd.engine.head import _conv3_weight, _npad, _pad1
@@ -400,20 +404,48 @@ def test_conv3d_halo_kernel(gpu, Cin, Cout, dil, D, H, W):
     nv = D * H * W
     zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
     outs = []
-    for halo in (1, 0):
-        _lib.set_option("conv_halo", halo)
-        out = torch.full((nv + 8, Cout), 7.0, dtype=torch.float16, device=gpu)
-        ops.conv3d(x.to(gpu), _conv3_weight(w).to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=Cin, D=D, H=H, W=W, dil=dil,
-                   cout=Cout, act=1)
-        outs.append(out)
-    _lib.set_option("conv_halo", 1)
+    try:
+        for halo in (2, 1, 0):
+            _lib.set_option("conv_halo", halo)
+            out = torch.full((nv + 8, Cout), 7.0, dtype=torch.float16, device=gpu)
+            ops.conv3d(x.to(gpu), _conv3_weight(w).to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=Cin, D=D, H=H, W=W, dil=dil,
+                       cout=Cout, act=1)
+            outs.append(out)
+    finally:
+        _lib.set_option("conv_halo", 2)
     ref = F.gelu(F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), hf(w).float(), b, padding="same", dilation=(dil, 1, 1)))
     ref = ref[0].permute(1, 2, 3, 0).reshape(nv, Cout)
     for out in outs:
         got = out[:nv].float().cpu()
         assert torch.allclose(got, ref, atol=3e-3, rtol=2e-3), float((got - ref).abs().max())
         assert torch.all(out[nv:].float() == 7.0)
-    assert float((outs[0][:nv].float() - outs[1][:nv].float()).abs().max()) <= 4e-3
+    assert float((outs[0][:nv].float() - outs[2][:nv].float()).abs().max()) <= 4e-3
+    assert float((outs[1][:nv].float() - outs[2][:nv].float()).abs().max()) <= 4e-3
+
+
+def test_conv3d_march_many_columns_reproducible(gpu):
+    """More columns x residues than resident workgroups (each workgroup marches several columns: the ring is re-filled
+    between them), no activation: bit-identical on repetition and equal to the implicit-GEMM kernel within fp32 re-ordering."""
+    from cryovit_amd import _lib
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _conv3_weight, _npad, _pad1
+
+    Cin, Cout, dil, D, H, W = 8, 8, 3, 7, 96, 640
+    g = torch.Generator(device=gpu).manual_seed(7)
+    x = torch.randn(D * H * W, Cin, device=gpu, generator=g).to(torch.float16)
+    w, b = rnd(Cout, Cin, 3, 3, 3, seed=61, scale=(27 * Cin) ** -0.5), rnd(Cout, seed=62)
+    zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
+    outs = []
+    try:
+        for halo in (2, 2, 0):
+            _lib.set_option("conv_halo", halo)
+            out = torch.zeros(D * H * W, Cout, dtype=torch.float16, device=gpu)
+            ops.conv3d(x, _conv3_weight(w).to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=Cin, D=D, H=H, W=W, dil=dil, cout=Cout, act=0)
+            outs.append(out)
+    finally:
+        _lib.set_option("conv_halo", 2)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0].float() - outs[2].float()).abs().max()) <= 4e-3
 
 
 @pytest.mark.parametrize("c2,c3", [(24, 16), (192, 128), (16, 8)])
