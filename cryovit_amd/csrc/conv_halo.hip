@@ -163,6 +163,13 @@ struct MarchCfg {
     static constexpr int LDS_BYTES = 4 * SLOT_BYTES + W_BYTES;
 };
 
+// C_in = 32: a voxel is 64 B, so the four 16-lane groups of a ds_read_b128 (16 consecutive voxels, lane group g reads 16-B
+// chunk g) would touch only a quarter of the banks, 2 .. 4 lanes each.  The ring therefore holds chunk c of halo voxel v at chunk
+// position c ^ 2 * ((v >> 2) & 1) -- applied on the SOURCE side of the LDS-DMA, whose LDS image is lane-linear: for both lane
+// patterns of a group ({0-3, 12-15} with one g and {4-11} with g ^ 1) and any alignment of the 16 voxels the 16 reads then hit
+// 16 distinct 16-B bank slots.
+__device__ __forceinline__ int ring_swizzle(int v) { return ((v >> 2) & 1) << 1; }
+
 template <int CIN, int NF, int ACT>
 __global__ __launch_bounds__(256) void k_conv3_march(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt /*[16 NF][ldw]*/,
                                                      long ldw, const float* __restrict__ bias, const void* __restrict__ zero_page,
@@ -200,7 +207,8 @@ __global__ __launch_bounds__(256) void k_conv3_march(const uint16_t* __restrict_
         tap = tap < 27 ? tap : 26;  // padded k: zero weights
         const int kz = tap / 9, r9 = tap - kz * 9, ky = r9 / 3, kx = r9 - ky * 3;
         fkz[s] = kz;
-        foff[s] = (((wave + ky) * CH_HX + li + kx) * CIN + c0) * 2;
+        const int hv = (wave + ky) * CH_HX + li + kx;  // halo voxel of fragment 0 (fragment f: + 16 f, same swizzle)
+        foff[s] = (hv * CIN + (CIN == 32 ? c0 ^ ring_swizzle(hv) * 8 : c0)) * 2;
     }
     const char* zp = (const char*)zero_page;
     __syncthreads();
@@ -220,7 +228,8 @@ __global__ __launch_bounds__(256) void k_conv3_march(const uint16_t* __restrict_
             const int hy = vox / CH_HX, hx = vox - hy * CH_HX;
             const int xx = x0 + hx, yy = y0 + hy;
             const bool ok = i < Cfg::NP && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H;
-            poff[q] = ok ? (uint32_t)(((yy * W + xx) * CIN + p * 8) * 2) : 0u;
+            const int ps = CIN == 32 ? p ^ ring_swizzle(vox) : p;  // the ring holds chunk ps of the voxel at chunk position p
+            poff[q] = ok ? (uint32_t)(((yy * W + xx) * CIN + ps * 8) * 2) : 0u;
             pvalid |= ok ? (1u << q) : 0u;
         }
         auto fetch = [&](int jp) {  // plane index jp (z = r + jp dil; -1 and J are padding planes) -> ring slot (jp + 1) & 3
@@ -241,30 +250,64 @@ __global__ __launch_bounds__(256) void k_conv3_march(const uint16_t* __restrict_
         fetch(0);
         fetch(1);
         const int y = ty * CH_TY + wave;
+        // A step's results are stored at the START of the next step, in front of that step's plane fetch: issued at the end of
+        // their own step they would be the youngest entries of the in-order vmcnt queue, and the wait for the fetched plane at
+        // the top of the next step would be a wait for their write acknowledgements (measured: 7 k instead of 3.5 k cycles / step).
+        uint2 pend[NF][4];
+        auto flush = [&](int z) {
+            uint16_t* orow = out + ((long)z * H + y) * W * cout;
+            if (y >= H) return;
+            if (swap8) {
+                if (4 * ge >= cout) return;
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const int x = tx * CH_TX + 16 * (f + 2 * (lane >> 5)) + li;
+                    if (x < W) *(uint2*)(orow + (long)x * cout + 4 * ge) = pend[0][f];
+                }
+                return;
+            }
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                if (16 * nf + 4 * g >= cout) continue;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int x = tx * CH_TX + 16 * f + li;
+                    if (x < W) *(uint2*)(orow + (long)x * cout + 16 * nf + 4 * g) = pend[nf][f];
+                }
+            }
+        };
         for (int j = 0; j < J; ++j) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // planes j-1, j, j+1 have landed (and step j-1's stores retired)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // planes j-1, j, j+1 have landed (step j-2's stores retired long ago)
             __builtin_amdgcn_s_barrier();                     // ... for every wave; step j-1's reads of slot (j+3)&3 are done
+            if (j > 0) flush(r + (j - 1) * dil);
             if (j + 2 <= J) fetch(j + 2);
             f32x4 acc[NF][4];
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
                 for (int f = 0; f < 4; ++f) acc[nf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // Fragment reads run PF k-steps ahead of the MFMAs that consume them (hipcc's own schedule kept one read in flight
+            // and waited for it in front of every MFMA: at one wave per SIMD the LDS latency was exposed 108 times per step)
+            constexpr int PF = CIN == 8 ? 1 : 3, NB = PF + 1;  // (C_in 8: four workgroups per CU hide it; more registers would cost one)
+            bf16x8 wf[NB][NF], xf[NB][4];
+            auto read_frags = [&](int s) {
+                const char* pl = ring + ((j + fkz[s]) & 3) * Cfg::SLOT_BYTES + foff[s];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) wf[s % NB][nf] = *(const bf16x8*)(wl + (16 * nf + li) * Cfg::WPITCH + 32 * s + 8 * g);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) xf[s % NB][f] = *(const bf16x8*)(pl + 16 * f * CIN * 2);
+            };
+#pragma unroll
+            for (int s = 0; s < PF; ++s) read_frags(s);
 #pragma unroll
             for (int s = 0; s < Cfg::KSTEPS; ++s) {
-                const char* pl = ring + ((j + fkz[s]) & 3) * Cfg::SLOT_BYTES + foff[s];
-                bf16x8 wf[NF];
+                if (s + PF < Cfg::KSTEPS) read_frags(s + PF);
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) wf[nf] = *(const bf16x8*)(wl + (16 * nf + li) * Cfg::WPITCH + 32 * s + 8 * g);
+                for (int f = 0; f < 4; ++f)
 #pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const bf16x8 xf = *(const bf16x8*)(pl + 16 * f * CIN * 2);
-#pragma unroll
-                    for (int nf = 0; nf < NF; ++nf) acc[nf][f] = mfma16x16x32<true>(wf[nf], xf, acc[nf][f]);
-                }
+                    for (int nf = 0; nf < NF; ++nf) acc[nf][f] = mfma16x16x32<true>(wf[s % NB][nf], xf[s % NB][f], acc[nf][f]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const int z = r + j * dil;
-            uint16_t* orow = out + ((long)z * H + y) * W * cout;
             if (swap8) {
                 // lanes 32-63 (groups 2, 3: padding rows of the 16-row weight fragment) take fragments 2 / 3 of lanes 0-31
 #pragma unroll
@@ -274,39 +317,22 @@ __global__ __launch_bounds__(256) void k_conv3_march(const uint16_t* __restrict_
                     acc[0][0][i] = __uint_as_float(a[0]);
                     acc[0][1][i] = __uint_as_float(b[0]);
                 }
-                if (y < H && 4 * ge < cout) {
-#pragma unroll
-                    for (int f = 0; f < 2; ++f) {
-                        const int x = tx * CH_TX + 16 * (f + 2 * (lane >> 5)) + li;
-                        if (x >= W) continue;
-                        float v[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float t = acc[0][f][i] + bv[0][i];
-                            v[i] = ACT == 1 ? gelu_erf(t) : t;
-                        }
-                        *(uint2*)(orow + (long)x * cout + 4 * ge) = uint2{pack2h(v[0], v[1]), pack2h(v[2], v[3])};
-                    }
-                }
-            } else if (y < H) {
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf) {
-                    if (16 * nf + 4 * g >= cout) continue;
-#pragma unroll
-                    for (int f = 0; f < 4; ++f) {
-                        const int x = tx * CH_TX + 16 * f + li;
-                        if (x >= W) continue;
-                        float v[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float t = acc[nf][f][i] + bv[nf][i];
-                            v[i] = ACT == 1 ? gelu_erf(t) : t;
-                        }
-                        *(uint2*)(orow + (long)x * cout + 16 * nf + 4 * g) = uint2{pack2h(v[0], v[1]), pack2h(v[2], v[3])};
-                    }
-                }
             }
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    if (swap8 && f >= 2) continue;
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = acc[nf][f][i] + bv[nf][i];
+                        v[i] = ACT == 1 ? gelu_erf(t) : t;
+                    }
+                    pend[nf][f] = uint2{pack2h(v[0], v[1]), pack2h(v[2], v[3])};
+                }
         }
+        if (J > 0) flush(r + (J - 1) * dil);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no DMA may be in flight when the workgroup releases its LDS)
 }
