@@ -82,11 +82,20 @@ struct Conv3Loader {
     int chunk[NJ];  // source 16-B chunk within the 64-wide K tile (swizzle folded in)
     bool rowok[NJ];
     int wave;
+    // C % 64 == 0 (every layer this loader still serves: the few-channel ones run in conv_halo.hip): a K tile lies inside ONE
+    // tap, so the tap, its (dz, dy, dx) and the channel offset are wave-uniform scalar work and a piece costs three adds, the
+    // bounds test and one 64-bit multiply-add.  The general form below divides by C and by 9 / 3 PER PIECE: ~60 vector
+    // instructions x 8 pieces per K tile against 32 MFMAs -- address arithmetic, not the L2, was what bounded sb1.c1 (658 TFLOP/s).
+    bool tap_uniform;
+    uint32_t inv_kpt;  // ceil(2^20 / (C / 64)): tap = kt * inv_kpt >> 20, exact for kt < 27 * C / 64 <= 864
+    int lin[NJ];       // linear voxel index of the piece's row
 
     __device__ __forceinline__ void init(const uint16_t* in_, const uint16_t* zero_, int C_, int D_, int H_, int W_,
                                          int dil_, long row0, long nvox, int tid) {
         in = in_; zero = zero_; C = C_; D = D_; H = H_; W = W_; dil = dil_;
         wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        tap_uniform = (C & 63) == 0 && C <= 2048 && nvox < (1L << 31);
+        inv_kpt = tap_uniform ? ((1u << 20) + (uint32_t)(C >> 6) - 1u) / (uint32_t)(C >> 6) : 0u;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int c = j * GEMM_THREADS + tid;
@@ -95,6 +104,7 @@ struct Conv3Loader {
             long v = row0 + row;
             rowok[j] = v < nvox;
             if (!rowok[j]) v = 0;
+            lin[j] = (int)v;
             x[j] = (int)(v % W);
             const long t = v / W;
             y[j] = (int)(t % H);
@@ -102,6 +112,24 @@ struct Conv3Loader {
         }
     }
     __device__ __forceinline__ void issue(char* lds_tile, int kt) const {
+        if (tap_uniform) {
+            const int tap = (int)(((uint32_t)kt * inv_kpt) >> 20);
+            const int c0 = kt * BK - tap * C;
+            const int kz = tap / 9, r9 = tap - kz * 9, ky = r9 / 3, kx = r9 - ky * 3;
+            const int dz = (kz - 1) * dil, dy = ky - 1, dx = kx - 1;
+            const int dlin = (dz * H + dy) * W + dx;
+            const bool tapok = tap < 27;  // (K padding: zero weights, zero data)
+            const uint16_t* base = in + c0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if ((ROWS * 8) % GEMM_THREADS != 0 && (j * GEMM_THREADS + wave * 64) >= ROWS * 8) break;
+                const bool ok = rowok[j] && tapok && (unsigned)(z[j] + dz) < (unsigned)D && (unsigned)(y[j] + dy) < (unsigned)H &&
+                                (unsigned)(x[j] + dx) < (unsigned)W;
+                const uint16_t* g = ok ? base + ((long)(lin[j] + dlin) * C + chunk[j] * 8) : zero;
+                glds16_vaddr(g, lds_addr(lds_tile) + (j * GEMM_THREADS + wave * 64) * 16);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if ((ROWS * 8) % GEMM_THREADS != 0 && (j * GEMM_THREADS + wave * 64) >= ROWS * 8) break;
