@@ -533,6 +533,7 @@ extern "C" int cvx_debug_read_gemm256p(unsigned long long* out96) {
 
 // few-channel 3x3x3 convolutions: 2 = z-marching LDS-ring kernel (default), 1 = per-tile halo kernel, 0 = implicit GEMM (A/B runs, tests)
 static std::atomic<int> g_conv_halo{2};
+static std::atomic<int> g_conv_wide{1};  // 192-wide implicit-GEMM tile for C_out % 192 == 0 (0: three 64-wide tiles)
 
 extern "C" int cvx_set_option(const char* name, int value) {
     if (!name) return cvx_fail("set_option: null name");
@@ -560,6 +561,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
         if (!one_of({0, 1, 2})) return cvx_fail("set_option: conv_halo is 0 (implicit GEMM), 1 (tile halo) or 2 (z-marching ring)");
         g_conv_halo = value;
     }
+    else if (!strcmp(name, "conv_wide")) g_conv_wide = value != 0;
     else if (!strcmp(name, "attn_variant")) {
         if (!one_of({0, 1, 3, 4, 5, 6}) && !(abl && one_of({10, 11, 12, 13})))
             return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");
@@ -693,6 +695,8 @@ static int conv3_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
     const long M = (long)d.D * d.H * d.W;
     EpiBF16<ACT, true> e{(uint16_t*)d.out, (long)d.cout, d.bias, M, (long)d.cout};  // head activations: fp16
     if (d.n_pad % 128 == 0) return launch_conv3<TileCfg<128, 128, 2>>(d, e, st);
+    // 192 output channels (sb1): all of them in one tile, so the gathered activation tile is fetched once instead of three times
+    if (d.n_pad % 192 == 0 && g_conv_wide) return launch_conv3<TileCfg<192, 128, 1>>(d, e, st);
     if (d.n_pad % 64 == 0) return launch_conv3<TileCfg<64, 256, 1>>(d, e, st);
     if (d.n_pad % 32 == 0) return launch_conv3<TileCfg<32, 256, 1>>(d, e, st);
     if (d.n_pad % 16 == 0) return launch_conv3<TileCfg<16, 256, 1>>(d, e, st);

@@ -385,6 +385,34 @@ def test_conv3d(gpu, Cin, Cout, dil, D, H, W):
     assert torch.all(out[nv:].float() == 7.0)
 
 
+def test_conv3d_wide_tile_matches_narrow(gpu):
+    """C_out = 192 (SynthesisBlock 1): the 192-wide implicit-GEMM tile against the three 64-wide tiles of the same call -- same
+    fp16 operands, same k order inside a tile, so the results are bit-identical; dilation 32 with D = 40 (taps on both sides)."""
+    from cryovit_amd import _lib
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _conv3_weight, _npad, _pad1
+
+    Cin, Cout, dil, D, H, W = 128, 192, 32, 40, 6, 7
+    x = hf(rnd(D, H, W, Cin, seed=63))
+    w, b = rnd(Cout, Cin, 3, 3, 3, seed=64, scale=(27 * Cin) ** -0.5), rnd(Cout, seed=65)
+    nv = D * H * W
+    zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
+    outs = []
+    try:
+        for wide in (1, 0):
+            _lib.set_option("conv_wide", wide)
+            out = torch.full((nv + 8, Cout), 7.0, dtype=torch.float16, device=gpu)
+            ops.conv3d(x.to(gpu), _conv3_weight(w).to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=Cin, D=D, H=H, W=W, dil=dil,
+                       cout=Cout, act=1)
+            outs.append(out)
+    finally:
+        _lib.set_option("conv_wide", 1)
+    ref = F.gelu(F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), hf(w).float(), b, padding="same", dilation=(dil, 1, 1)))
+    ref = ref[0].permute(1, 2, 3, 0).reshape(nv, Cout)
+    assert torch.allclose(outs[0][:nv].float().cpu(), ref, atol=3e-3, rtol=2e-3)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("Cin,Cout,dil,D,H,W", [(32, 16, 2, 7, 9, 70), (16, 16, 1, 5, 12, 131), (8, 8, 1, 4, 7, 66), (16, 8, 3, 6, 4, 64),
                                                (32, 12, 1, 3, 5, 33), (32, 32, 8, 19, 6, 40), (32, 32, 4, 9, 10, 65), (8, 4, 1, 1, 3, 5),
                                                (16, 32, 5, 4, 5, 17), (8, 8, 2, 11, 13, 129)])
