@@ -1,8 +1,9 @@
 """Loader feeding the segmentation head (mirror of the inference half of
 ``/root/reference/src/cryovit/datasets/tomo_dataset.py:16-146`` and ``datamodules/utils.py:13-121``).
 
-Training-only behaviour (the random crop of l.148-178) belongs to SURVEY s.8f row N4 and is not built: ``train=True`` is
-refused.
+``train=True`` adds the training-side random crop of l.148-178 (SURVEY s.8f row N4): depth at most 128, 32 x 32 feature
+positions (512 x 512 voxels of the label), drawn with ``numpy.random.choice`` in the reference's order so that a seeded
+run crops the same windows.
 """
 
 from __future__ import annotations
@@ -34,8 +35,6 @@ class TomoDataset(Dataset):
 
     def __init__(self, records, input_key: str, label_key: str, split_key: str | None = "split_id", data_root=".", aux_keys=None,
                  train: bool = False) -> None:
-        if train:
-            raise NotImplementedError("TomoDataset(train=True): the training-side random crop is out of scope of this build")
         self.records = _as_records(records)
         self.input_key, self.label_key, self.split_key = input_key, label_key, split_key
         self.aux_keys = list(aux_keys or [])
@@ -50,6 +49,8 @@ class TomoDataset(Dataset):
             raise IndexError
         record = self.records[idx]
         data = self._load_tomogram(record)
+        if self.train:
+            self._random_crop(data)
         return TomogramData(sample=record["sample"], tomo_name=record["tomo_name"], split_id=data.get("split_id"),
                             data=torch.from_numpy(np.ascontiguousarray(data["input"])),
                             label=torch.from_numpy(np.ascontiguousarray(data["label"])),
@@ -83,6 +84,38 @@ class TomoDataset(Dataset):
             if ok:
                 out[key] = io.read_dataset(path, key)
         return out
+
+
+def random_crop_window(shape_dhw, input_key: str, rng=np.random):
+    """tomo_dataset.py:155-170: (di, hi, wi, depth, side, side) of the crop in INPUT coordinates, or None when the input already
+    has the crop's size.  Three ``choice`` draws (depth, height, width), each only when that axis has room."""
+    max_depth = 128
+    side = 32 if input_key == "dino_features" else 512
+    d, h, w = (int(v) for v in shape_dhw)
+    x, y, z = min(d, max_depth), side, side
+    if (d, h, w) == (x, y, z):
+        return None
+    delta_d, delta_h, delta_w = d - x + 1, h - y + 1, w - z + 1
+    di = rng.choice(delta_d) if delta_d > 0 else 0
+    hi = rng.choice(delta_h) if delta_h > 0 else 0
+    wi = rng.choice(delta_w) if delta_w > 0 else 0
+    return int(di), int(hi), int(wi), x, y, z
+
+
+def _random_crop(self, data: dict) -> None:
+    """In place on ``data['input']`` ([..., D, h, w]) and ``data['label']`` ([D, H, W]); with ``dino_features`` the label window
+    is the feature window times 16 (tomo_dataset.py:172-178)."""
+    win = random_crop_window(data["input"].shape[-3:], self.input_key)
+    if win is None:
+        return
+    di, hi, wi, x, y, z = win
+    data["input"] = data["input"][..., di : di + x, hi : hi + y, wi : wi + z]
+    if self.input_key == "dino_features":
+        hi, wi, y, z = 16 * hi, 16 * wi, 16 * y, 16 * z
+    data["label"] = data["label"][di : di + x, hi : hi + y, wi : wi + z]
+
+
+TomoDataset._random_crop = _random_crop
 
 
 def collate_fn(batch: list[TomogramData]) -> BatchedTomogramData:

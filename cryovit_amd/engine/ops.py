@@ -189,6 +189,39 @@ def dice_sums(probs: torch.Tensor, labels: torch.Tensor, dice: torch.Tensor, thr
          thr)
 
 
+# ---- training-side pieces (SURVEY s.8f N4) ----
+
+
+def dice_loss_forward(probs: torch.Tensor, labels: torch.Tensor, out4: torch.Tensor) -> None:
+    """out4 (fp32[4], device) = I, Sy, Sp, loss over labels > -1; probs fp32 contiguous, labels int8 of the same numel."""
+    dev = _dev_check(probs, labels, out4)
+    if probs.dtype != torch.float32 or labels.dtype != torch.int8 or probs.numel() != labels.numel() or out4.numel() < 4:
+        raise _lib.CvxError("dice_loss_forward: probs fp32, labels int8 of the same size, out4 fp32[4]")
+    if not (probs.is_contiguous() and labels.is_contiguous()):
+        raise _lib.CvxError("dice_loss_forward: contiguous tensors required")
+    call(dev, "cvx_dice_loss_forward", _lib.load().cvx_dice_loss_forward, probs.data_ptr(), labels.data_ptr(), probs.numel(),
+         dice_scratch(probs.device).data_ptr(), out4.data_ptr())
+
+
+def dice_loss_backward(probs, logits, labels: torch.Tensor, sums4: torch.Tensor, grad_out: float, grad: torch.Tensor,
+                       through_sigmoid: bool = False) -> None:
+    dev = _dev_check(probs, logits, labels, sums4, grad)
+    if labels.dtype != torch.int8 or grad.dtype != torch.float32 or grad.numel() != labels.numel():
+        raise _lib.CvxError("dice_loss_backward: labels int8, grad fp32 of the same size")
+    call(dev, "cvx_dice_loss_backward", _lib.load().cvx_dice_loss_backward, _p(probs), _p(logits), labels.data_ptr(), labels.numel(),
+         sums4.data_ptr(), float(grad_out), int(through_sigmoid), grad.data_ptr())
+
+
+def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float, beta1: float, beta2: float,
+               eps: float, weight_decay: float, step: int) -> None:
+    dev = _dev_check(p, g, m, v)
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+            raise _lib.CvxError("adamw_step: four contiguous fp32 tensors of one size")
+    call(dev, "cvx_adamw_step", _lib.load().cvx_adamw_step, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+         float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step))
+
+
 # ---- alternate encoder (SAM2 Hiera) ----
 
 

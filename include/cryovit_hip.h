@@ -176,6 +176,27 @@ int cvx_conv3_out_fused(const void* in, const float* w, float bias, float* logit
 int cvx_dice_sums(const float* probs, const int8_t* labels, float* dice, long n, float thr, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Training-side pieces of the head (csrc/train.hip).
+ *
+ * cvx_dice_loss_forward -- replaces DiceLoss.forward (/root/reference/src/cryovit/models/losses.py:17-32) applied to the
+ *   masked predictions of BaseModel._masked_predict (models/base_model.py:91-112): over the n voxels with label > -1,
+ *   out4 = { I = sum y p, Sy = sum y, Sp = sum p, loss = 1 - 2 I / (Sy + Sp + 1e-3) }.  probs fp32 (16-B aligned), labels int8
+ *   in {-1, 0, 1}; scratch: >= 3*CVX_DICE_BLOCKS floats.  Block partials + fixed-order finalize: bitwise reproducible.
+ * cvx_dice_loss_backward -- what autograd derives for that expression: grad[i] = grad_out * (-2 y_i / den + 2 I / den^2) for
+ *   label > -1, 0 elsewhere (den = Sy + Sp + 1e-3; sums4 = the forward's out4, on the device).  through_sigmoid = 1 continues
+ *   through p = sigmoid(clip(logit, -5, 5)) (models/cryovit.py:39,49): * p (1 - p), and 0 where |logits[i]| >= 5 (logits
+ *   nullable: the clipped logits the forward stored).
+ * cvx_adamw_step -- one torch.optim.AdamW step (the optimizer of BaseModel.configure_optimizers, models/base_model.py:57-63)
+ *   over flat fp32 arrays (16-B aligned), in place, same order of operations as torch's single-tensor path:
+ *   p *= 1 - lr wd; m += (1 - b1)(g - m); v = b2 v + (1 - b2) g^2; p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+ * --------------------------------------------------------------------------------------------------- */
+int cvx_dice_loss_forward(const float* probs, const int8_t* labels, long n, float* scratch, float* out4, hipStream_t stream);
+int cvx_dice_loss_backward(const float* probs, const float* logits, const int8_t* labels, long n, const float* sums4, float grad_out,
+                           int through_sigmoid, float* grad, hipStream_t stream);
+int cvx_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int step, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Alternate encoder: SAM2.1 Hiera image encoder + FPN neck (BASELINE configs[4]).  These entry points, together with
  * cvx_gemm_bf16 (qkv / proj / MLP / patch-embed / lateral convs) and cvx_layernorm_bf16, replace
  * `self.model.image_encoder(flat_data)` and the resize in front of it -- SAM2.forward_features,

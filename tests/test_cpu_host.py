@@ -305,7 +305,7 @@ def _write_tomo(path, D=4, with_data=True, seed=0):
 
 def test_tomo_dataset_and_datamodule_records(tmp_path):
     """tomo_dataset.py:89-146 + single/multi_sample_datamodule.py: record selection, item contents (input as stored, uint8
-    raw input scaled and given a channel axis, aux keys that exist, split id), collate metadata, refusal of train=True."""
+    raw input scaled and given a channel axis, aux keys that exist, split id), collate metadata, train=True."""
     import csv
 
     import pytest
@@ -360,8 +360,11 @@ def test_tomo_dataset_and_datamodule_records(tmp_path):
     assert list(raw.aux_data) == ["labels/mito"]
     with pytest.raises(AssertionError, match="Label key 'cristae' not found"):
         TomoDataset([("Q109", "a.hdf")], input_key="data", label_key="cristae", data_root=root)[0]
-    with pytest.raises(NotImplementedError):
-        TomoDataset([("Q109", "a.hdf")], input_key="data", label_key="mito", data_root=root, train=True)
+    # train=True: the random crop of tomo_dataset.py:148-178 (a 3 x 32 x 48 raw volume is smaller than 512 x 512: numpy slicing
+    # past the end keeps what is there, like the reference)
+    np.random.seed(3)
+    tr = TomoDataset([("Q109", "a.hdf")], input_key="data", label_key="mito", data_root=root, train=True)[0]
+    assert tuple(tr.data.shape) == (1, 3, 32, 48) and tuple(tr.label.shape) == (3, 32, 48)
     with pytest.raises(ValueError, match="No testing data"):
         SingleSampleDataModule(["Q53"], None, "split_id", split_file=tmp_path / "csv" / "splits.csv", dataset_fn=dataset_fn).test_dataset()
 
