@@ -16,6 +16,25 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
+def t1_layers():
+    """(layer, algorithmic FLOPs, compulsory bytes in + out) of the 28 launches of one head forward at [1,1536,128,32,32] (SURVEY App. B;
+    fp16 activations, fp32 probabilities, int8 labels), in launch order."""
+    D, h = 128, 32
+    nv = D * h * h
+    L = [("layers.0 1x1x1 1536->1024 +GELU", 2.0 * nv * 1536 * 1024, nv * (1536 + 1024) * 2)]
+    H = h
+    for bi, (c1, c2, c3) in enumerate(((1024, 192, 128), (128, 64, 32), (32, 32, 32), (32, 16, 8))):
+        n = D * H * H
+        L += [(f"sb{bi + 1} GroupNorm stats", 0.0, n * c1 * 2), (f"sb{bi + 1} GroupNorm finalize", 0.0, 0.0), (f"sb{bi + 1} GroupNorm apply", 0.0, n * c1 * 4),
+              (f"sb{bi + 1}.conv1 {c1}->{c2} +GELU", 2.0 * n * 27 * c1 * c2, n * (c1 + c2) * 2), (f"sb{bi + 1}.conv2 {c2}->{c2} +GELU", 2.0 * n * 27 * c2 * c2, n * c2 * 4),
+              (f"sb{bi + 1}.convT {c2}->{c3} x4 +GELU", 2.0 * n * 4 * c2 * c3, n * (c2 + 4 * c3) * 2)]
+        H *= 2
+    n = D * H * H
+    L += [("output_layer.0 8->8 +GELU", 2.0 * n * 27 * 64, n * 32), ("output_layer.2 8->1 + clip + sigmoid + Dice", 2.0 * n * 27 * 8, n * (16 + 4 + 1)),
+          ("dice finalize", 0.0, 0.0)]
+    return L
+
+
 def summarize(d: str) -> None:
     f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
     rows = [r for r in csv.DictReader(open(f)) if "cvx::" in r["Kernel_Name"] or "cvx" in r["Kernel_Name"]]
@@ -29,12 +48,17 @@ def summarize(d: str) -> None:
     fw = [rows[e - per + 1 : e + 1] for e in ends[1:]]
     fw = [x for x in fw if len(x) == per]
     tot = 0.0
+    layers = t1_layers() if per == 28 else None
     for k in range(per):
         dur = [int(x[k]["End_Timestamp"]) - int(x[k]["Start_Timestamp"]) for x in fw]
         ms = sum(dur) / len(dur) / 1e6
         tot += ms
-        n = fw[0][k]["Kernel_Name"].replace("cvx::", "")
-        print(f"{k:3d} {ms:8.3f} ms  grid {fw[0][k].get('Grid_Size', '?'):>9s} wg {fw[0][k].get('Workgroup_Size', '?'):>4s}  {n[:110]}")
+        n = fw[0][k]["Kernel_Name"].replace("cvx::", "").split("(")[0]
+        if layers:
+            name, fl, by = layers[k]
+            print(f"{k:3d} {ms:7.3f} ms {fl / ms / 1e9 if fl else 0:7.0f} TFLOP/s {by / ms / 1e9 if by else 0:6.2f} TB/s (compulsory)  {name:44s} {n[:70]}")
+        else:
+            print(f"{k:3d} {ms:8.3f} ms  {n[:110]}")
     span = [(int(x[-1]["End_Timestamp"]) - int(x[0]["Start_Timestamp"])) / 1e6 for x in fw]
     print(f"sum of kernels {tot:.3f} ms, first-start to last-end {sum(span) / len(span):.3f} ms over {len(fw)} forwards")
 
