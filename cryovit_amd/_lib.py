@@ -18,6 +18,7 @@ EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT, EP
 DTYPE_BF16, DTYPE_F16 = 0, 1  # CVX_DTYPE_*
 DICE_BLOCKS = 4096  # CVX_DICE_BLOCKS
 GN_BLOCKS = 1024  # CVX_GN_BLOCKS
+GN_MAX_GROUPS = 512  # CVX_GN_MAX_GROUPS
 
 c_long, c_int, c_float, c_void_p = C.c_long, C.c_int, C.c_float, C.c_void_p
 
@@ -34,7 +35,7 @@ class GemmDesc(C.Structure):
         ("pos", c_void_p), ("ldpos", c_long),
         ("npatch", c_int), ("ntp", c_int), ("tok0", c_int),
         ("heads", c_int), ("kp", c_int),
-        ("H", c_int), ("W", c_int), ("cout", c_int), ("act", c_int), ("dtype", c_int),
+        ("H", c_int), ("W", c_int), ("cout", c_int), ("act", c_int), ("dtype", c_int), ("convt_up_z", c_int),
     ]
 
 
@@ -98,6 +99,10 @@ SIGNATURES = {
     "cvx_set_gemm_event_hook": (c_int, [c_int, c_void_p, c_void_p, c_int]),
     "cvx_get_gemm_event_count": (c_int, []),
     "cvx_conv3d_f16": (c_int, [C.POINTER(Conv3dDesc), c_void_p]),
+    "cvx_conv2s2_f16": (c_int, [C.POINTER(Conv3dDesc), c_void_p]),
+    "cvx_concat_channels_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
+    "cvx_pointwise_out_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "cvx_groupnorm_act_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "cvx_layernorm_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
     "cvx_attention_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cvx_preprocess_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -251,19 +251,22 @@ template <int ACT, bool HALF = false>
 struct EpiConvT {
     static constexpr bool F16 = HALF;
     uint16_t* out; const float* bias; int H, W, cout; long m_valid, n_valid;
+    int up_z = 0;  // 1: kernel = stride = (2,2,2) (UNet3D's upconv, unet3d.py:166-170): n = ((iz*2+i)*2+j)*Cout + o, output [2D][2H][2W][Cout]
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
     __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const { load_vec<NV>(c.bias, bias + n0); }
     template <int NV>
     __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
         if (m >= m_valid) return;
-        const long xq = m % W, t = m / W, yq = t % H, zq = t / H;
+        const long xq = m % W, t = m / W, yq = t % H, zq0 = t / H;
         constexpr int CH = NV >= 8 ? 8 : 4;
 #pragma unroll
         for (int h = 0; h < NV / CH; ++h) {
             const long n = n0 + h * CH;
             if (n >= n_valid) continue;
-            const int ij = (int)(n / cout), o = (int)(n - (long)ij * cout);
+            const int ijk = (int)(n / cout), o = (int)(n - (long)ijk * cout);
+            const int ij = ijk & 3;
+            const long zq = up_z ? 2 * zq0 + (ijk >> 2) : zq0;
             float v[CH];
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
@@ -316,6 +319,61 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_conv3_nreg(const uint16_t* in,
     Conv3Loader<Cfg::BL> ldl;
     ldr.init(Wt, ldw, (long)tr * Cfg::BR, threadIdx.x);
     ldl.init(in, zero, C, D, H, W, dil, (long)tl * Cfg::BL, (long)D * H * W, threadIdx.x);
+    gemm_tile_body<Cfg>(ldr, ldl, epi, nk, (long)tr * Cfg::BR, (long)tl * Cfg::BL, smem);
+}
+
+// Conv3d kernel = stride = 2 (UNet3D's pooling convolution, unet3d.py:127-131) as an implicit GEMM: row = output voxel,
+// K index = ((iz*2+iy)*2+ix)*C + c gathered from the 2x2x2 input voxels it covers (never out of the volume; rows past the last
+// output voxel read the zero page).  C is a power of two >= 8, so 8 C is a multiple of the 64-deep K tile.
+template <int ROWS>
+struct Pool2Loader {
+    static constexpr int NJ = (ROWS * 8 + GEMM_THREADS - 1) / GEMM_THREADS;
+    const uint16_t* in;
+    const uint16_t* zero;
+    int cshift, Hi, Wi;
+    long vin[NJ];  // linear index of input voxel (2z, 2y, 2x)
+    int chunk[NJ];
+    bool rowok[NJ];
+    int wave;
+    __device__ __forceinline__ void init(const uint16_t* in_, const uint16_t* zero_, int cshift_, int Do, int Ho, int Wo, long row0, int tid) {
+        in = in_; zero = zero_; cshift = cshift_; Hi = 2 * Ho; Wi = 2 * Wo;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const long nvox = (long)Do * Ho * Wo;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = j * GEMM_THREADS + tid;
+            const int row = c >> 3, pos = c & 7;
+            chunk[j] = pos ^ swz_chunk(row);
+            long v = row0 + row;
+            rowok[j] = v < nvox;
+            if (!rowok[j]) v = 0;
+            const long x = v % Wo, t = v / Wo, y = t % Ho, z = t / Ho;
+            vin[j] = ((2 * z) * Hi + 2 * y) * Wi + 2 * x;
+        }
+    }
+    __device__ __forceinline__ void issue(char* lds_tile, int kt) const {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if ((ROWS * 8) % GEMM_THREADS != 0 && (j * GEMM_THREADS + wave * 64) >= ROWS * 8) break;
+            const int kk = kt * BK + chunk[j] * 8;
+            const int tap = kk >> cshift, c = kk - (tap << cshift);
+            const long vs = vin[j] + ((long)(tap >> 2) * Hi + ((tap >> 1) & 1)) * Wi + (tap & 1);
+            const uint16_t* g = (rowok[j] && tap < 8) ? in + ((vs << cshift) + c) : zero;
+            glds16_vaddr(g, lds_addr(lds_tile) + (j * GEMM_THREADS + wave * 64) * 16);
+        }
+    }
+};
+
+template <class Cfg, class Epi>
+__global__ __launch_bounds__(GEMM_THREADS) void k_pool2_nreg(const uint16_t* in, const uint16_t* zero, int cshift, int Do, int Ho, int Wo,
+                                                              const uint16_t* Wt, long ldw, int nk, int tiles_n, int tiles_m, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tr, tl;
+    tile_coords(blockIdx.x, gridDim.x, tiles_n, tiles_m, tr, tl);
+    PlainLoader<Cfg::BR, Cfg::FRG> ldr;
+    Pool2Loader<Cfg::BL> ldl;
+    ldr.init(Wt, ldw, (long)tr * Cfg::BR, threadIdx.x);
+    ldl.init(in, zero, cshift, Do, Ho, Wo, (long)tl * Cfg::BL, threadIdx.x);
     gemm_tile_body<Cfg>(ldr, ldl, epi, nk, (long)tr * Cfg::BR, (long)tl * Cfg::BL, smem);
 }
 
@@ -516,6 +574,18 @@ static int launch_conv3(const cvx_conv3d_desc& d, const Epi& epi, hipStream_t st
     return cvx_check_launch();
 }
 
+template <class Cfg, class Epi>
+static int launch_pool2(const cvx_conv3d_desc& d, int cshift, const Epi& epi, hipStream_t st) {
+    const int Do = d.D / 2, Ho = d.H / 2, Wo = d.W / 2;
+    const long M = (long)Do * Ho * Wo;
+    const int tiles_n = (int)(d.n_pad / Cfg::BR), tiles_m = (int)((M + Cfg::BL - 1) / Cfg::BL);
+    auto k = k_pool2_nreg<Cfg, Epi>;
+    CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, (const uint16_t*)d.in, (const uint16_t*)d.zero_page,
+                       cshift, Do, Ho, Wo, (const uint16_t*)d.w, (long)d.k_pad, (int)(d.k_pad / BK), tiles_n, tiles_m, epi);
+    return cvx_check_launch();
+}
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -672,17 +742,17 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
             if (d->cout % 8) return cvx_fail("gemm: ConvT C_out must be a multiple of 8");
             if (d->dtype == CVX_DTYPE_F16) {  // the head's activations are fp16
                 if (d->act) {
-                    EpiConvT<1, true> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+                    EpiConvT<1, true> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n, d->convt_up_z ? 1 : 0};
                     return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
                 }
-                EpiConvT<0, true> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+                EpiConvT<0, true> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n, d->convt_up_z ? 1 : 0};
                 return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
             }
             if (d->act) {
-                EpiConvT<1> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+                EpiConvT<1> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n, d->convt_up_z ? 1 : 0};
                 return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
             }
-            EpiConvT<0> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n};
+            EpiConvT<0> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n, d->convt_up_z ? 1 : 0};
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         default:
@@ -708,6 +778,29 @@ bool conv3_halo_eligible(const cvx_conv3d_desc& d);
 int conv3_halo_dispatch(const cvx_conv3d_desc& d, hipStream_t st);
 bool conv3_march_eligible(const cvx_conv3d_desc& d);
 int conv3_march_dispatch(const cvx_conv3d_desc& d, hipStream_t st);
+}
+
+template <int ACT>
+static int pool2_dispatch(const cvx_conv3d_desc& d, int cshift, hipStream_t st) {
+    const long M = (long)(d.D / 2) * (d.H / 2) * (d.W / 2);
+    EpiBF16<ACT, true> e{(uint16_t*)d.out, (long)d.cout, d.bias, M, (long)d.cout};
+    if (d.n_pad % 128 == 0) return launch_pool2<TileCfg<128, 128, 2>>(d, cshift, e, st);
+    if (d.n_pad % 64 == 0) return launch_pool2<TileCfg<64, 256, 1>>(d, cshift, e, st);
+    if (d.n_pad % 32 == 0) return launch_pool2<TileCfg<32, 256, 1>>(d, cshift, e, st);
+    if (d.n_pad % 16 == 0) return launch_pool2<TileCfg<16, 256, 1>>(d, cshift, e, st);
+    return cvx_fail("conv2s2: C_out must be padded to a multiple of 16");
+}
+
+extern "C" int cvx_conv2s2_f16(const cvx_conv3d_desc* d, hipStream_t st) {
+    if (!d) return cvx_fail("conv2s2: null descriptor");
+    if (!d->in || !d->w || !d->bias || !d->out || !d->zero_page) return cvx_fail("conv2s2: null pointer");
+    if (d->D % 2 || d->H % 2 || d->W % 2 || d->D <= 0 || d->H <= 0 || d->W <= 0) return cvx_fail("conv2s2: D, H, W must be even");
+    int cshift = 3;
+    while ((1 << cshift) < d->C) ++cshift;
+    if ((1 << cshift) != d->C || d->C < 8) return cvx_fail("conv2s2: C_in must be a power of two >= 8");
+    if (d->k_pad != 8 * d->C) return cvx_fail("conv2s2: K must be 8*C_in");
+    if (d->cout % 4) return cvx_fail("conv2s2: C_out must be a multiple of 4");
+    return d->act ? pool2_dispatch<1>(*d, cshift, st) : pool2_dispatch<0>(*d, cshift, st);
 }
 
 extern "C" int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t st) {

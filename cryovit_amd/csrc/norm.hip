@@ -247,8 +247,9 @@ __global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x
     extern __shared__ float red[];  // [2*C] channel sums | channel sums of squares
     __shared__ float part[256][17]; // one row per thread: s[8] | q[8]
     const int tid = threadIdx.x;
-    const int cpt = C >> 3;         // 16-B chunks per voxel (power of two <= 256)
-    const int cc = tid % cpt, vsub = tid / cpt, vstride = 256 / cpt;
+    const int cpt = C >> 3;         // 16-B chunks per voxel (<= 256); cpt * vstride threads are active
+    const int cc = tid % cpt, vstride = 256 / cpt;
+    const int vsub = tid / cpt < vstride ? tid / cpt : -1;
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const uint16_t* __restrict__ x
     // four 16-B loads in flight per thread (a block covers 64+ voxels: enough blocks to fill the chip even at C = 1024);
     // the order in which a thread adds its voxels is the same with and without the unrolling
     const uint16_t* xp = x + cc * 8;
-    long v = v0 + vsub;
+    long v = vsub < 0 ? v1 : v0 + vsub;
     for (; v + 3 * vstride < v1; v += 4 * vstride) {
         const uint4 u0 = ld_stream16(xp + v * C), u1 = ld_stream16(xp + (v + vstride) * C);
         const uint4 u2 = ld_stream16(xp + (v + 2 * vstride) * C), u3 = ld_stream16(xp + (v + 3 * vstride) * C);
@@ -321,11 +322,13 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ pa
     }
 }
 
+template <int ACT>
 __global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x, const float* __restrict__ coef,
                                                   uint16_t* __restrict__ out, long nvox, int C, long vox_per_block) {
     const int tid = threadIdx.x;
     const int cpt = C >> 3;
     const int cc = tid % cpt, vsub = tid / cpt, vstride = 256 / cpt;
+    if (vsub >= vstride) return;
     float sc[8], sh[8];
     {
         const float4 a0 = *(const float4*)(coef + cc * 8), a1 = *(const float4*)(coef + cc * 8 + 4);
@@ -333,12 +336,16 @@ __global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x
         sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
         sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
     }
+    auto fn = [&](float v, int e) {
+        const float t = fmaf(v, sc[e], sh[e]);
+        return ACT == 1 ? gelu_erf(t) : t;  // (UNet3D: InstanceNorm + GELU in one pass)
+    };
     auto norm = [&](const uint4& u) {
         uint4 o;
-        o.x = pack2h(fmaf(hlo(u.x), sc[0], sh[0]), fmaf(hhi(u.x), sc[1], sh[1]));
-        o.y = pack2h(fmaf(hlo(u.y), sc[2], sh[2]), fmaf(hhi(u.y), sc[3], sh[3]));
-        o.z = pack2h(fmaf(hlo(u.z), sc[4], sh[4]), fmaf(hhi(u.z), sc[5], sh[5]));
-        o.w = pack2h(fmaf(hlo(u.w), sc[6], sh[6]), fmaf(hhi(u.w), sc[7], sh[7]));
+        o.x = pack2h(fn(hlo(u.x), 0), fn(hhi(u.x), 1));
+        o.y = pack2h(fn(hlo(u.y), 2), fn(hhi(u.y), 3));
+        o.z = pack2h(fn(hlo(u.z), 4), fn(hhi(u.z), 5));
+        o.w = pack2h(fn(hlo(u.w), 6), fn(hhi(u.w), 7));
         return o;
     };
     const long v0 = (long)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
@@ -392,12 +399,12 @@ extern "C" int cvx_features_to_channels_last(const void* feats_f16, void* out_cl
     return cvx_check_launch();
 }
 
-extern "C" int cvx_groupnorm_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
-                                  int G, float eps, hipStream_t st) {
+static int groupnorm_impl(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C, int G, float eps,
+                          int act, hipStream_t st) {
     if (nvox <= 0) return 0;
     const int cpt = C / 8;
-    if (C % 8 || cpt > 256 || (cpt & (cpt - 1)) || C % G || G > 128)
-        return cvx_fail("groupnorm: C must be 8*2^k <= 2048, divisible by G, G <= 128");
+    if (C % 8 || cpt > 256 || C % G || G > CVX_GN_MAX_GROUPS)
+        return cvx_fail("groupnorm: C must be a multiple of 8, <= 2048, divisible by G, G <= 512");
     // stats[0 .. 2G) = the sums; then per-block partials of nstat blocks; the per-channel coefficients (2C floats = C/G more
     // "blocks") behind them: 2G * (1 + CVX_GN_BLOCKS) floats in all
     const int vstride = 256 / cpt;
@@ -416,6 +423,18 @@ extern "C" int cvx_groupnorm_f16(const void* x, const float* w, const float* b, 
     if (rc) return rc;
     const long vox_per_block = 8L * vstride;                     // 8 voxels per thread, four 16-B loads in flight
     const unsigned nblk = (unsigned)((nvox + vox_per_block - 1) / vox_per_block);
-    hipLaunchKernelGGL(k_gn_apply, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, nvox, C, vox_per_block);
+    if (act) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, nvox, C, vox_per_block);
+    else hipLaunchKernelGGL(k_gn_apply<0>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, nvox, C, vox_per_block);
     return cvx_check_launch();
+}
+
+extern "C" int cvx_groupnorm_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
+                                  int G, float eps, hipStream_t st) {
+    return groupnorm_impl(x, w, b, out, stats, nvox, C, G, eps, 0, st);
+}
+
+extern "C" int cvx_groupnorm_act_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
+                                      int G, float eps, int act, hipStream_t st) {
+    if (act != 0 && act != 1) return cvx_fail("groupnorm_act: act is 0 (none) or 1 (GELU)");
+    return groupnorm_impl(x, w, b, out, stats, nvox, C, G, eps, act, st);
 }

@@ -70,7 +70,7 @@ def call(dev: torch.device, what: str, fn, *args) -> None:
 
 
 def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, *, m: int, n: int,
-         gamma=None, pos=None, npatch=0, ntp=0, tok0=0, heads=0, kp=0, H=0, W=0, cout=0, act=0, ldc=None) -> None:
+         gamma=None, pos=None, npatch=0, ntp=0, tok0=0, heads=0, kp=0, H=0, W=0, cout=0, act=0, ldc=None, convt_up_z=0) -> None:
     """C = A W^T with a fused epilogue.  a: bf16 [M_alloc, lda]; w: bf16 [n_pad, k_pad] (packed).  fp16 operands (both a and
     w) select the fp16 MFMA and fp16 outputs (plain / GELU / ConvT epilogues: the segmentation head)."""
     dev = _dev_check(a, w, out, bias, gamma, pos)
@@ -87,6 +87,7 @@ def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bia
     d.pos, d.ldpos = _p(pos), (pos.stride(0) if pos is not None else 0)
     d.npatch, d.ntp, d.tok0, d.heads, d.kp = npatch, ntp, tok0, heads, kp
     d.H, d.W, d.cout, d.act = H, W, cout, act
+    d.convt_up_z = convt_up_z
     d.dtype = _lib.DTYPE_F16 if a.dtype == torch.float16 else _lib.DTYPE_BF16
     call(dev, "cvx_gemm_bf16", _lib.load().cvx_gemm_bf16, C.byref(d))
 
@@ -99,6 +100,32 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tens
     d.C, d.D, d.H, d.W, d.dil, d.cout = Cin, D, H, W, dil, cout
     d.n_pad, d.k_pad, d.act = w.shape[0], w.shape[1], act
     call(dev, "cvx_conv3d_f16", _lib.load().cvx_conv3d_f16, C.byref(d))
+
+
+def conv2s2(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, zero_page: torch.Tensor, *, Cin: int, D: int, H: int,
+            W: int, cout: int, act: int) -> None:
+    """nn.Conv3d(Cin, cout, 2, stride=2) on a channels-last fp16 volume [D,H,W,Cin] -> [D/2,H/2,W/2,cout]; w fp16 [n_pad, 8*Cin]."""
+    dev = _dev_check(x, w, bias, out, zero_page)
+    d = Conv3dDesc()
+    d.in_, d.w, d.bias, d.zero_page, d.out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), zero_page.data_ptr(), out.data_ptr()
+    d.C, d.D, d.H, d.W, d.dil, d.cout = Cin, D, H, W, 1, cout
+    d.n_pad, d.k_pad, d.act = w.shape[0], w.shape[1], act
+    call(dev, "cvx_conv2s2_f16", _lib.load().cvx_conv2s2_f16, C.byref(d))
+
+
+def concat_channels(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, nvox: int, Ca: int, Cb: int) -> None:
+    dev = _dev_check(a, b, out)
+    if a.dtype != torch.float16 or b.dtype != torch.float16 or out.dtype != torch.float16 or out.numel() < nvox * (Ca + Cb):
+        raise _lib.CvxError("concat_channels: fp16 tensors, out >= nvox*(Ca+Cb) elements")
+    call(dev, "cvx_concat_channels_f16", _lib.load().cvx_concat_channels_f16, a.data_ptr(), Ca, b.data_ptr(), Cb, out.data_ptr(), nvox)
+
+
+def pointwise_out(x: torch.Tensor, w: torch.Tensor, bias: float, logits, probs, *, nvox: int, Cdim: int) -> None:
+    dev = _dev_check(x, w, logits, probs)
+    if x.dtype != torch.float16 or w.dtype != torch.float32 or w.numel() < Cdim:
+        raise _lib.CvxError("pointwise_out: x fp16 [nvox, C], w fp32 [C]")
+    call(dev, "cvx_pointwise_out_f16", _lib.load().cvx_pointwise_out_f16, x.data_ptr(), w.data_ptr(), float(bias), _p(logits), _p(probs), nvox,
+         Cdim)
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, rows: int, Cdim: int, eps: float) -> None:
@@ -156,10 +183,15 @@ def gn_stats_size(G: int) -> int:
 
 
 def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, stats: torch.Tensor, *, nvox: int,
-              Cdim: int, G: int, eps: float) -> None:
+              Cdim: int, G: int, eps: float, act: int = 0) -> None:
+    """GroupNorm (G = C: InstanceNorm3d with affine) over a channels-last fp16 volume, optionally with GELU fused (act=1)."""
     dev = _dev_check(x, w, b, out, stats)
     if stats.dtype != torch.float32 or stats.numel() < gn_stats_size(G):
         raise _lib.CvxError(f"groupnorm: stats must be fp32 with >= {gn_stats_size(G)} elements (2*G*(1+CVX_GN_BLOCKS))")
+    if act:
+        call(dev, "cvx_groupnorm_act_f16", _lib.load().cvx_groupnorm_act_f16, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(),
+             stats.data_ptr(), nvox, Cdim, G, eps, act)
+        return
     call(dev, "cvx_groupnorm_f16", _lib.load().cvx_groupnorm_f16, x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(),
          stats.data_ptr(), nvox, Cdim, G, eps)
 

@@ -83,6 +83,8 @@ typedef struct cvx_gemm_desc {
     int H, W, cout, act;       /* CONVT: input plane size, C_out, act (0 none / 1 GELU) */
     int dtype;                 /* CVX_DTYPE_BF16 (0, default): bf16 operands / 16-bit outputs; CVX_DTYPE_F16: fp16 operands
                                   and outputs (BF16, BF16_GELU and CONVT epilogues only: the segmentation head) */
+    int convt_up_z;            /* CONVT: 0 = kernel/stride (1,2,2), N = 4*C_out (the head); 1 = (2,2,2), N = 8*C_out with
+                                  n = ((iz*2+i)*2+j)*C_out + o, output [2D][2H][2W][C_out] (UNet3D upconv, unet3d.py:166-170) */
 } cvx_gemm_desc;
 
 int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t stream);
@@ -103,6 +105,17 @@ typedef struct cvx_conv3d_desc {
     int C, D, H, W, dil, cout, n_pad, k_pad, act;
 } cvx_conv3d_desc;
 int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t stream);
+
+/* nn.Conv3d(C, cout, 2, stride=2) (UNet3D's pooling convolution, models/unet3d.py:127-131) on the same descriptor: in fp16
+ * [D][H][W][C] (D, H, W even, C a power of two >= 8) -> out fp16 [D/2][H/2][W/2][cout] = act(conv + bias); w fp16 [n_pad][8*C]
+ * with k = ((iz*2+iy)*2+ix)*C + c; dil is ignored. */
+int cvx_conv2s2_f16(const cvx_conv3d_desc* d, hipStream_t stream);
+
+/* UNet3D helpers (csrc/unet.hip).  cvx_concat_channels_f16: out[v][0..Ca) = a[v][:], out[v][Ca..Ca+Cb) = b[v][:] (torch.cat along
+ * channels, unet3d.py:64; Ca, Cb multiples of 8).  cvx_pointwise_out_f16: the 1x1x1 output layer + clip + sigmoid
+ * (unet3d.py:45,69-71,96): logits / probs fp32 [nvox] (either nullable) from in fp16 [nvox][C], w fp32 [C], C <= 64, a multiple of 8. */
+int cvx_concat_channels_f16(const void* a, int Ca, const void* b, int Cb, void* out, long nvox, hipStream_t stream);
+int cvx_pointwise_out_f16(const void* in, const float* w, float bias, float* logits, float* probs, long nvox, int C, hipStream_t stream);
 
 /* LayerNorm over the last dim of an fp32 token stream -> bf16 (GEMM operand).  eps inside the sqrt.
  * x fp32 [rows][ldx], out bf16 [rows][ldo].  Replaces nn.LayerNorm(C, eps=1e-6) in the hub ViT blocks. */
@@ -149,14 +162,19 @@ int cvx_im2col_patches(const float* x, int b, int Hi, int Wi, void* out, int k_p
 /* fp16 [C][D][h][w] (the HDF5 `dino_features` layout) -> fp16 channels-last [D][h][w][C] (a transpose: exact) */
 int cvx_features_to_channels_last(const void* feats_f16, void* out_cl, int C, long nvox, hipStream_t stream);
 
-/* GroupNorm over a channels-last fp16 volume x[nvox][C], G groups (<= 128), biased variance, eps inside sqrt
+/* GroupNorm over a channels-last fp16 volume x[nvox][C], G groups (<= 512), biased variance, eps inside sqrt
  * (nn.GroupNorm(G, C, eps=1e-3) -- cryovit.py:69).  Three launches: per-block partial sums, fixed-order reduction (no
  * atomics: results are bitwise reproducible) that also leaves the per-channel affine coefficients, apply -> fp16 out.
  * stats: fp32 scratch of 2*G*(1 + CVX_GN_BLOCKS) floats (stats[0..2G) = sum | sum of squares per group after the call;
  * block partials and the 2*C coefficients behind them). */
 #define CVX_GN_BLOCKS 1024
+#define CVX_GN_MAX_GROUPS 512
 int cvx_groupnorm_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
                        int G, float eps, hipStream_t stream);
+/* The same with an activation fused into the apply pass (act: 0 none, 1 exact GELU).  G = C is
+ * nn.InstanceNorm3d(C, eps, affine=True) of the UNet3D baseline (models/unet3d.py:19-25,127-140). */
+int cvx_groupnorm_act_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
+                           int G, float eps, int act, hipStream_t stream);
 
 /* Last layer of the head at full resolution, channels-last fp16 in[D][H][W][8]:
  *   conv3x3x3(8->1, w fp32 [27][8] tap-major) + bias, clip(+-5) -> logits fp32 (nullable), sigmoid -> probs fp32

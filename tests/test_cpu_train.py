@@ -64,3 +64,26 @@ def test_random_crop_mirror_matches_reference_fixture(gold):
         i0, l0 = int(d["input"][0, 0, 0, 0]), int(d["label"][0, 0, 0])
         got = [i0 // (h * w), (i0 // w) % h, i0 % w, *d["input"].shape[-3:], l0 // (h * up * w * up), (l0 // (w * up)) % (h * up), l0 % (w * up), *d["label"].shape]
         assert got == [int(v) for v in want]
+
+
+def test_unet3d_oracle_reproduces_reference_fixture_and_mirror_layout(gold):
+    """The UNet3D oracle (pinned bit-for-bit against the reference's classes when the fixture was written) reproduces the
+    fixture here; the product's parameter container has the reference's state_dict keys and shapes, loads strictly, and the
+    Hydra-style config instantiates it."""
+    from cryovit_amd.config import compose, instantiate
+    from cryovit_amd.models import UNet3D
+    from oracle import unet3d as ou
+
+    g = gold("unet3d_narrow.npz")
+    orc = ou.UNet3D(ou.NARROW_WIDTHS)
+    ou.rescaled_init_(orc, seed=int(g["seed"]))
+    with torch.no_grad():
+        probs = orc.forward_tomo_batch(torch.from_numpy(g["vol"]))
+    assert torch.allclose(probs, torch.from_numpy(g["probs"]), atol=2e-6)
+    ref, mine = ou.UNet3D(ou.REF_WIDTHS).state_dict(), UNet3D(device="cpu").state_dict()
+    assert list(ref) == list(mine) and all(ref[k].shape == mine[k].shape for k in ref) and len(ref) == 82
+    UNet3D(device="cpu", widths=ou.NARROW_WIDTHS).load_state_dict(orc.state_dict(), strict=True)
+    cfg = compose("eval_model", ["model=unet3d", "datamodule=single", "datamodule.sample=[Q109]", "datamodule.split_id=1", "label_key=mito",
+                                 "paths.model_dir=/m", "paths.data_dir=/d", "paths.exp_dir=/e"])
+    model = instantiate(cfg.model, device="cpu")
+    assert isinstance(model, UNet3D) and model.input_key == "data" and model.lr == 3e-3 and set(model.metric_fns) == {"dice_metric", "f1_metric"}

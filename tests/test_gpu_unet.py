@@ -1,0 +1,142 @@
+"""UNet3D baseline (SURVEY s.8f row N4) on the HIP kernels against the oracle restatement, which oracle/make_golden_unet.py pinned
+bit-for-bit against the reference's own classes (models/unet3d.py:12-216) before writing tests/golden/unet3d_narrow.npz.
+fp16 storage + fp32 accumulation against an fp32 CPU run: tolerances as for the CryoVIT head."""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def hf(t):
+    return t.to(torch.float16)
+
+
+@pytest.mark.parametrize("C,Cout,D,H,W", [(8, 8, 4, 6, 10), (16, 64, 6, 8, 8), (64, 256, 2, 4, 6), (32, 24, 8, 2, 2)])
+def test_conv2s2(gpu, C, Cout, D, H, W):
+    """nn.Conv3d(C, Cout, 2, stride=2) as an implicit GEMM over 2x2x2 voxel groups."""
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _npad, _pad1, _pad2
+
+    x = hf(rnd(D, H, W, C, seed=80))
+    w, b = rnd(Cout, C, 2, 2, 2, seed=81, scale=(8 * C) ** -0.5), rnd(Cout, seed=82)
+    nvo = D * H * W // 8
+    out = torch.full((nvo + 8, Cout), 7.0, dtype=torch.float16, device=gpu)
+    zero = torch.zeros(256, dtype=torch.uint8, device=gpu)
+    wp = _pad2(w.permute(0, 2, 3, 4, 1).reshape(Cout, 8 * C), _npad(Cout), 8 * C)
+    ops.conv2s2(x.to(gpu), wp.to(gpu), _pad1(b, _npad(Cout)).to(gpu), out, zero, Cin=C, D=D, H=H, W=W, cout=Cout, act=0)
+    ref = F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), hf(w).float(), b, stride=2)[0].permute(1, 2, 3, 0).reshape(nvo, Cout)
+    got = out[:nvo].float().cpu()
+    assert torch.allclose(got, ref, atol=3e-3, rtol=2e-3), float((got - ref).abs().max())
+    assert torch.all(out[nvo:].float() == 7.0)
+
+
+@pytest.mark.parametrize("c2,c3", [(32, 16), (16, 8), (256, 64)])
+def test_conv_transpose_3d(gpu, c2, c3):
+    """nn.ConvTranspose3d(c2, c3, 2, stride=2): GEMM with N = 8*c3 and the 3-D pixel-shuffle epilogue."""
+    from cryovit_amd._lib import EPI_CONVT
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _npad, _pad1, _pad2
+
+    D, H, W = 3, 4, 5
+    nv = D * H * W
+    x = hf(rnd(nv, c2, seed=83))
+    wt, b = rnd(c2, c3, 2, 2, 2, seed=84, scale=c2**-0.5), rnd(c3, seed=85)
+    A = torch.zeros(ops.alloc_rows(nv) * c2 + 4096, dtype=torch.float16)
+    A[: nv * c2] = x.reshape(-1)
+    A = A.to(gpu)
+    a2 = torch.as_strided(A, (ops.alloc_rows(nv), c2), (c2, 1))
+    wg = wt.permute(2, 3, 4, 1, 0).reshape(8 * c3, c2)
+    out = torch.zeros(2 * D, 2 * H, 2 * W, c3, dtype=torch.float16, device=gpu)
+    ops.gemm(EPI_CONVT, a2, _pad2(wg, _npad(8 * c3), ops.round_up(c2, 64)).to(gpu), out, _pad1(b.repeat(8), _npad(8 * c3)).to(gpu),
+             m=nv, n=8 * c3, H=H, W=W, cout=c3, act=0, ldc=c3, convt_up_z=1)
+    xin = x.float().reshape(D, H, W, c2).permute(3, 0, 1, 2).unsqueeze(0)
+    ref = F.conv_transpose3d(xin, hf(wt).float(), b, stride=2)[0].permute(1, 2, 3, 0)
+    assert torch.allclose(out.float().cpu(), ref, atol=3e-3, rtol=2e-3), float((out.float().cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("C", [16, 48, 384])
+def test_instance_norm_gelu(gpu, C):
+    """G = C (InstanceNorm3d, affine, eps 1e-3) with the GELU fused; C / 8 not a power of two (48 -> 6, 384 -> 48 chunks)."""
+    from cryovit_amd.engine import ops
+
+    D, H, W = 4, 6, 5
+    x = hf(rnd(D, H, W, C, seed=86) * 1.5 + 0.3)
+    w, b = rnd(C, seed=87) * 0.2 + 1, rnd(C, seed=88) * 0.2
+    out = torch.zeros_like(x, device=gpu)
+    stats = torch.zeros(ops.gn_stats_size(C), device=gpu)
+    ops.groupnorm(x.to(gpu), w.to(gpu), b.to(gpu), out, stats, nvox=D * H * W, Cdim=C, G=C, eps=1e-3, act=1)
+    ref = F.gelu(F.instance_norm(x.float().permute(3, 0, 1, 2).unsqueeze(0), weight=w, bias=b, eps=1e-3))[0].permute(1, 2, 3, 0)
+    assert torch.allclose(out.float().cpu(), ref, atol=4e-3, rtol=2e-3), float((out.float().cpu() - ref).abs().max())
+
+
+def test_concat_and_pointwise_out(gpu):
+    from cryovit_amd.engine import ops
+
+    nv, Ca, Cb = 1000, 16, 24
+    a, b = hf(rnd(nv, Ca, seed=89)), hf(rnd(nv, Cb, seed=90))
+    out = torch.zeros(nv, Ca + Cb, dtype=torch.float16, device=gpu)
+    ops.concat_channels(a.to(gpu), b.to(gpu), out, nvox=nv, Ca=Ca, Cb=Cb)
+    assert torch.equal(out.cpu(), torch.cat([a, b], 1))
+    w = rnd(16, seed=91)
+    logits, probs = torch.zeros(nv, device=gpu), torch.zeros(nv, device=gpu)
+    ops.pointwise_out((a * 3).to(gpu), w.to(gpu), 0.25, logits, probs, nvox=nv, Cdim=16)
+    ref = ((a * 3).float() @ w + 0.25).clip(-5, 5)
+    assert torch.allclose(logits.cpu(), ref, atol=1e-4, rtol=1e-4) and torch.allclose(probs.cpu(), torch.sigmoid(ref), atol=1e-5)
+    assert float(ref.abs().max()) == 5.0  # the clip is exercised
+
+
+def test_unet3d_narrow_against_reference_fixture(gpu, gold):
+    """The whole model (narrow family, reference-layout state_dict from the oracle's seeded init) on a [20, 40, 37] volume that
+    needs padding on every axis: probabilities against the fixture the reference's own classes produced."""
+    from cryovit_amd.models import UNet3D
+    from oracle import unet3d as ou
+
+    g = gold("unet3d_narrow.npz")
+    orc = ou.UNet3D(ou.NARROW_WIDTHS)
+    ou.rescaled_init_(orc, seed=int(g["seed"]))
+    model = UNet3D(device=gpu, widths=ou.NARROW_WIDTHS)
+    model.load_state_dict(orc.state_dict(), strict=True)
+    vol = torch.from_numpy(g["vol"])  # [1, D, 1, H, W]
+
+    class Batch:
+        tomo_batch = vol
+
+    probs = model(Batch()).cpu()
+    want = torch.from_numpy(g["probs"])
+    assert tuple(probs.shape) == tuple(want.shape) == (1, 20, 40, 37)
+    err = (probs - want).abs()
+    # logits: the clipped fp32 logits of the padded volume; fp16 storage through 23 layers with 15 InstanceNorms
+    _, lg = model.engine().forward_volume(F.pad(vol[0, :, 0], (0, 48 - 37, 0, 48 - 40, 0, 32 - 20)).to(gpu), want_logits=True)
+    lerr = (lg.cpu() - torch.from_numpy(g["logits_padded"])[0, 0]).abs()
+    print(f"unet3d narrow: prob err max {float(err.max()):.2e} mean {float(err.mean()):.2e}; logit err max {float(lerr.max()):.2e} mean {float(lerr.mean()):.2e}")
+    # measured 1.2e-1 / 3.1e-3 (logits, |logit| up to 5) and 8.2e-3 / 5.0e-4 (probabilities): fp16 storage through 23 layers, 15 of
+    # them InstanceNorms that rescale the round-off of 8-channel activations
+    assert float(lerr.max()) <= 2e-1 and float(lerr.mean()) <= 6e-3
+    assert float(err.max()) <= 1.5e-2 and float(err.mean()) <= 1.5e-3
+    agree = ((probs >= 0.5) == (want >= 0.5)).float().mean()
+    assert float(agree) >= 0.999
+
+
+def test_unet3d_reference_widths_runs_and_matches_oracle(gpu):
+    """Reference widths (16 / 64 / 256 | 384) on a [16, 32, 32] volume against the oracle on the CPU."""
+    from cryovit_amd.engine.unet3d import UNet3DEngine
+    from oracle import unet3d as ou
+
+    orc = ou.UNet3D(ou.REF_WIDTHS)
+    ou.rescaled_init_(orc, seed=17)
+    vol = torch.rand(16, 32, 32, generator=torch.Generator().manual_seed(18))
+    with torch.no_grad():
+        want = torch.clip(orc.forward_volume(vol[None, None]), -5, 5)[0, 0]
+    eng = UNet3DEngine(orc.state_dict(), gpu)
+    probs, lg = eng.forward_volume(vol.to(gpu), want_logits=True)
+    lerr = (lg.cpu() - want).abs()
+    print(f"unet3d ref widths: logit err max {float(lerr.max()):.2e} mean {float(lerr.mean()):.2e}")
+    assert float(lerr.max()) <= 2e-1 and float(lerr.mean()) <= 8e-3
+    assert torch.allclose(probs.cpu(), torch.sigmoid(lg.cpu()), atol=1e-6)
