@@ -17,5 +17,15 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
     rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o pmc -- python3 "$REPO/tools/run_one_gemm.py" > "$OUT/pmc_$name.log" 2>&1
     echo "[profile] pmc $name done"
 done
+# attention: instruction mix and pipe occupancy
+for pass in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
+    name=attn_$(echo "$pass" | cut -d' ' -f1)
+    rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -o pmc -- python3 "$REPO/tools/run_one_attention.py" > "$OUT/pmc_$name.log" 2>&1
+    echo "[profile] pmc $name done"
+done
+# configs[2] alone: per-launch table of the head
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/head" -o head -- python3 "$REPO/tools/bench_head.py" 5 > "$OUT/head.log" 2>&1
+echo "[profile] head trace done"
 cd "$REPO"
+python3 tools/bench_head.py --summarize "$OUT/head" > "$OUT/head_launches.txt"
 python3 tools/summarize_profiles.py "$TAG"

@@ -30,10 +30,38 @@ for name in ("bench_under_rocprof.log",):
     if (src / name).exists():
         (dst / f"{tag}_{name}").write_text((src / name).read_text())
 
+if (src / "head_launches.txt").exists():
+    (dst / f"{tag}_head_launches.txt").write_text((src / "head_launches.txt").read_text())
+
+# ---- attention kernel: instruction mix / pipe occupancy per launch ----
+avals: dict[str, list[float]] = {}
+arows = []
+for f in glob.glob(str(src / "pmc_attn_*" / "**" / "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_attention" in r["Kernel_Name"]:
+            avals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            arows.append({"dispatch": r["Dispatch_Id"], "counter": r["Counter_Name"], "value": r["Counter_Value"], "start_ns": r["Start_Timestamp"],
+                          "end_ns": r["End_Timestamp"], "vgpr": r["VGPR_Count"], "lds": r["LDS_Block_Size"], "grid": r["Grid_Size"], "wg": r["Workgroup_Size"]})
+if arows:
+    with open(dst / f"{tag}_pmc_attention.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(arows[0]))
+        w.writeheader()
+        w.writerows(arows)
+    am = {k: sum(v[1:]) / max(1, len(v) - 1) for k, v in avals.items()}
+    a = {"kernel": "k_attention<0> (default variant), 128 slices x 24 heads x 1029 tokens, head_dim 64", "per_launch_means": am}
+    if "SQ_INSTS_MFMA" in am and "SQ_INSTS_VALU" in am:
+        a["valu_per_mfma"] = am["SQ_INSTS_VALU"] / am["SQ_INSTS_MFMA"]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in am and "SQ_BUSY_CYCLES" in am:
+        a["note"] = "SQ_VALU_MFMA_BUSY_CYCLES / SQ_ACTIVE_INST_VALU are summed over SIMDs; compare with 4 x SQ_BUSY_CYCLES-per-SE totals as in DESIGN.md s.4"
+    (dst / f"{tag}_attention_counters.json").write_text(json.dumps(a, indent=1))
+    print(json.dumps(a, indent=1))
+
 vals: dict[str, list[float]] = {}
 dur: list[float] = []
 out_rows = []
 for f in glob.glob(str(src / "pmc_*" / "**" / "*counter_collection.csv"), recursive=True):
+    if "pmc_attn_" in f:
+        continue
     for r in csv.DictReader(open(f)):
         if DOM in r["Kernel_Name"]:
             vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
