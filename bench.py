@@ -187,6 +187,51 @@ def stage_breakdown(vit, head, vol, labels, feats_cl, feats_f16, sb: int) -> dic
     return {k: round(v, 3) for k, v in out.items()}
 
 
+def other_configs(dev, vol) -> dict:
+    """Outside the timed region, rank 0 at N = 1: BASELINE configs[4] (sam_features: SAM2.1 Hiera-L image encoder + FPN neck over
+    the same tomogram) and the reference's baseline model, UNet3D, on the raw tomogram (SURVEY s.8f N4) -- one untimed warm-up,
+    then HIP-event time of one tomogram each; synthetic weights."""
+    import torch
+
+    from cryovit_amd.engine.unet3d import UNet3DEngine
+    from cryovit_amd.models import UNet3D, load_sam_encoder
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    out = {}
+    voxels = vol.numel()
+    enc = load_sam_encoder("SAM2", synthetic_seed=2, device=dev, slice_batch=64)
+    outs = enc._outs(D_)
+
+    def sam():
+        for d0 in range(0, D_, 64):
+            enc.engine.encode(vol[d0 : d0 + 64], outs, d0)
+
+    ms = timed(sam)
+    out["configs[4] sam_features (SAM2.1 Hiera-L + FPN), one tomogram"] = {"ms": round(ms, 3), "voxels_per_s": voxels / ms * 1e3,
+                                                                           "tflops": enc.engine.flops(D_) / ms / 1e9}
+    del enc, outs
+    torch.cuda.empty_cache()
+    model = UNet3D(device="cpu")
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * ((2.0 / max(1, p[0].numel())) ** 0.5 if p.dim() > 1 else 0.1) + (1.0 if p.dim() == 1 and name.endswith(("1.weight", "4.weight")) else 0.0))
+    eng = UNet3DEngine(model.state_dict(), dev)
+    volf = vol.float() / 255.0
+    ms = timed(lambda: eng.forward(volf))
+    out["UNet3D baseline (models/unet3d.py) forward, one raw tomogram"] = {"ms": round(ms, 3), "voxels_per_s": voxels / ms * 1e3}
+    return out
+
+
 def cpu_baseline() -> dict:
     """torch-CPU fp32 oracle on a bounded sample of the same workload (SURVEY s.8d 'CPU reference timing'): ViT-g/14-reg on
     k = 2 slices of 448x448, the head on [1,1536,128,8,8] (FULL depth, so dilation / padding / GroupNorm behave as in the real
@@ -462,6 +507,11 @@ def main() -> None:
                                                "tflops": head.flops(D_, hp, wp) / st["head_ms"] / 1e9,
                                                "compulsory_GBps": head_bytes / st["head_ms"] / 1e6, "hbm_peak_GBps": PEAK_HBM_TBS * 1e3},
             }
+            if world == 1:
+                try:
+                    line["configs"].update(other_configs(dev, vols[0]))
+                except Exception as e:  # the extra configurations must never cost the headline line
+                    line["configs"]["other_configs_error"] = f"{type(e).__name__}: {e}"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

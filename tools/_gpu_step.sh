@@ -1,4 +1,8 @@
 set -e -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_unet.py -x -q -m gpu -s > gpurun_out/s2_unet_tests.log 2>&1 || { tail -60 gpurun_out/s2_unet_tests.log; exit 1; }
-tail -8 gpurun_out/s2_unet_tests.log
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/s2_bench_b.json 2> gpurun_out/s2_bench_b.err || { tail -20 gpurun_out/s2_bench_b.err; exit 1; }
+python - <<PY
+import json
+d=json.load(open("gpurun_out/s2_bench_b.json"))
+print(round(d["ms_per_step"],2)); print(json.dumps(d["configs"], indent=1))
+PY
