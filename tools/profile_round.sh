@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round profiles, run ON THE GPU BOX (gpurun): kernel-trace stats of the benchmark command, then the PMC passes of the dominant
 # kernel (the SwiGLU w12 GEMM alone, tools/run_one_gemm.py) -- counters in their own runs, never combined with tracing.
-#   bash tools/profile_round.sh r02        -> gpurun_out/prof_r02/...   (tools/summarize_profiles.py r02 copies the summaries)
+#   bash tools/profile_round.sh r02        -> gpurun_out/prof_r02/...   (then, in the BUILD container where gpurun merged the files back:
+#   python tools/summarize_profiles.py r02 copies the summaries into the tracked profiles/ directory)
 set -e -o pipefail
 TAG=${1:-r02}
 OUT=$PWD/gpurun_out/prof_$TAG
