@@ -588,6 +588,11 @@ static int launch_pool2(const cvx_conv3d_desc& d, int cshift, const Epi& epi, hi
 
 }  // namespace cvx
 
+namespace cvx {  // convt.hip: few-channel (1,2,2) transposed convolutions without LDS / K padding
+bool convt_small_eligible(const cvx_gemm_desc& d);
+int convt_small_dispatch(const cvx_gemm_desc& d, hipStream_t st);
+}
+
 using namespace cvx;
 
 extern std::atomic<int> g_attn_variant, g_attn_xcd_remap;  // attention.hip
@@ -603,6 +608,7 @@ extern "C" int cvx_debug_read_gemm256p(unsigned long long* out96) {
 
 // few-channel 3x3x3 convolutions: 2 = z-marching LDS-ring kernel (default), 1 = per-tile halo kernel, 0 = implicit GEMM (A/B runs, tests)
 static std::atomic<int> g_conv_halo{2};
+static std::atomic<int> g_convt_small{1};  // dedicated kernel for the head's 16->8 and 32->32 transposed convolutions (0: GEMM tile)
 static std::atomic<int> g_conv_wide{1};  // 192-wide implicit-GEMM tile for C_out % 192 == 0 (0: three 64-wide tiles)
 
 extern "C" int cvx_set_option(const char* name, int value) {
@@ -632,6 +638,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
         g_conv_halo = value;
     }
     else if (!strcmp(name, "conv_wide")) g_conv_wide = value != 0;
+    else if (!strcmp(name, "convt_small")) g_convt_small = value != 0;
     else if (!strcmp(name, "attn_variant")) {
         if (!one_of({0, 1, 3, 4, 5, 6}) && !(abl && one_of({10, 11, 12, 13})))
             return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");
@@ -740,6 +747,7 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         }
         case CVX_EPI_CONVT: {
             if (d->cout % 8) return cvx_fail("gemm: ConvT C_out must be a multiple of 8");
+            if (g_convt_small && convt_small_eligible(*d)) return convt_small_dispatch(*d, st);
             if (d->dtype == CVX_DTYPE_F16) {  // the head's activations are fp16
                 if (d->act) {
                     EpiConvT<1, true> e{(uint16_t*)d->out, d->bias, d->H, d->W, d->cout, d->m, d->n, d->convt_up_z ? 1 : 0};

@@ -13,16 +13,20 @@ namespace cvx {
 // L2 bandwidth: 14.5 GB of cache traffic for a 537-MB input).  Dice partial sums stay in registers and leave the block as
 // ONE row of `partials` (no same-address atomics: 1.5 M of them cost 19 ms on this volume).
 constexpr int CO_TX = 64, CO_TY = 4, CO_HX = CO_TX + 2, CO_HY = CO_TY + 2;
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ in, const float* __restrict__ w /*[27][8]*/,
                                                    float bias, float* __restrict__ logits, float* __restrict__ probs,
                                                    const int8_t* __restrict__ labels, float* __restrict__ partials,
                                                    uint8_t* __restrict__ mask, float mask_thr, int D, int H, int W, int tiles_x,
                                                    int tiles_y, long ntiles) {
-    __shared__ float sw[27 * 8];
+    // weights as fp16 pairs (the reference runs this layer under fp16 autocast like the others): a tap is four v_dot2_f32_f16
+    // (fp16 products, fp32 accumulation) instead of eight conversions + eight FMAs -- the kernel was bound by those ~430 vector
+    // instructions per voxel, not by HBM (0.51 ms = 1.4 TB/s of compulsory traffic)
+    __shared__ __attribute__((aligned(16))) uint32_t sw2[27 * 4];
     __shared__ float red[3][4];
     __shared__ __attribute__((aligned(16))) uint4 halo[3][CO_HY][CO_HX];  // 19 KB
-    for (int i = threadIdx.x; i < 27 * 8; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < 27 * 4; i += 256) sw2[i] = pack2h(w[2 * i], w[2 * i + 1]);
     float inter = 0.f, ysum = 0.f, psum = 0.f;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -50,11 +54,11 @@ __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ 
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const uint4 u = halo[kz][ly + ky][lx + kx];
-                    const float* ww = sw + ((kz * 3 + ky) * 3 + kx) * 8;
-                    acc = fmaf(hlo(u.x), ww[0], acc); acc = fmaf(hhi(u.x), ww[1], acc);
-                    acc = fmaf(hlo(u.y), ww[2], acc); acc = fmaf(hhi(u.y), ww[3], acc);
-                    acc = fmaf(hlo(u.z), ww[4], acc); acc = fmaf(hhi(u.z), ww[5], acc);
-                    acc = fmaf(hlo(u.w), ww[6], acc); acc = fmaf(hhi(u.w), ww[7], acc);
+                    const uint4 ww = *(const uint4*)(sw2 + ((kz * 3 + ky) * 3 + kx) * 4);
+                    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u.x), __builtin_bit_cast(h16x2, ww.x), acc, false);
+                    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u.y), __builtin_bit_cast(h16x2, ww.y), acc, false);
+                    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u.z), __builtin_bit_cast(h16x2, ww.z), acc, false);
+                    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u.w), __builtin_bit_cast(h16x2, ww.w), acc, false);
                 }
         const float lg = fminf(fmaxf(acc, -5.0f), 5.0f);            // cryovit.py:39
         const float p = 1.0f / (1.0f + __expf(-lg));                 // cryovit.py:49

@@ -499,6 +499,40 @@ def test_conv_transpose(gpu, c2, c3):
     assert torch.allclose(out.float().cpu(), ref, atol=3e-3, rtol=2e-3), float((out.float().cpu() - ref).abs().max())
 
 
+@pytest.mark.parametrize("c2,c3,D,H,W", [(16, 8, 3, 5, 32), (32, 32, 2, 3, 16), (16, 8, 1, 1, 16), (32, 32, 5, 7, 48)])
+def test_conv_transpose_small_kernel(gpu, c2, c3, D, H, W):
+    """The dedicated (1,2,2) transposed-convolution kernel of the few-channel blocks (16 -> 8, 32 -> 32; W % 16 == 0) against torch
+    and against the GEMM-tile path of the same call (option off)."""
+    from cryovit_amd import _lib
+    from cryovit_amd._lib import EPI_CONVT
+    from cryovit_amd.engine import ops
+    from cryovit_amd.engine.head import _npad, _pad1, _pad2
+
+    nv = D * H * W
+    x = hf(rnd(nv, c2, seed=66))
+    wt, b = rnd(c2, c3, 1, 2, 2, seed=67, scale=c2**-0.5), rnd(c3, seed=68)
+    A = torch.zeros(ops.alloc_rows(nv) * c2 + 4096, dtype=torch.float16)
+    A[: nv * c2] = x.reshape(-1)
+    A = A.to(gpu)
+    a2 = torch.as_strided(A, (ops.alloc_rows(nv), c2), (c2, 1))
+    wg = wt[:, :, 0].permute(2, 3, 1, 0).reshape(4 * c3, c2)
+    wp, bp = _pad2(wg, _npad(4 * c3), ops.round_up(c2, 64)).to(gpu), _pad1(b.repeat(4), _npad(4 * c3)).to(gpu)
+    outs = []
+    try:
+        for small in (1, 0):
+            _lib.set_option("convt_small", small)
+            out = torch.full((D, 2 * H, 2 * W, c3), 7.0, dtype=torch.float16, device=gpu)
+            ops.gemm(EPI_CONVT, a2, wp, out, bp, m=nv, n=4 * c3, H=H, W=W, cout=c3, act=1, ldc=c3)
+            outs.append(out)
+    finally:
+        _lib.set_option("convt_small", 1)
+    xin = x.float().reshape(D, H, W, c2).permute(3, 0, 1, 2).unsqueeze(0)
+    ref = F.gelu(F.conv_transpose3d(xin, hf(wt).float(), b, stride=(1, 2, 2)))[0].permute(1, 2, 3, 0)
+    for out in outs:
+        assert torch.allclose(out.float().cpu(), ref, atol=3e-3, rtol=2e-3), float((out.float().cpu() - ref).abs().max())
+    assert float((outs[0].float() - outs[1].float()).abs().max()) <= 2e-3
+
+
 def test_conv3_out_fused_and_dice(gpu, gold):
     from cryovit_amd.engine import ops
 
@@ -514,7 +548,8 @@ def test_conv3_out_fused_and_dice(gpu, gold):
                         dice, D=D, H=H, W=W, mask=seg, mask_threshold=0.3)
     # the uint8 segmentation PredictionWriter stores: bit-exact (preds >= threshold) of the GPU's own probabilities
     assert torch.equal(seg.cpu(), (probs.cpu() >= 0.3).to(torch.uint8))
-    ref = F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), w, torch.tensor([b]), padding="same")[0, 0].clip(-5, 5)
+    # (the weights are rounded to fp16 inside the kernel -- fp16 autocast of the reference -- and a tap is four v_dot2_f32_f16)
+    ref = F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), hf(w).float(), torch.tensor([b]), padding="same")[0, 0].clip(-5, 5)
     assert torch.allclose(logits.cpu(), ref, atol=1e-4, rtol=1e-4)
     assert torch.allclose(probs.cpu(), torch.sigmoid(ref), atol=1e-5)
     # Dice sums must be exact integers given the GPU's own probabilities
