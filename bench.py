@@ -351,6 +351,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slice-batch", type=int, default=128, help="slices per ViT launch sequence (reference default 128)")
     ap.add_argument("--streams", type=int, default=1, help="tomograms in flight per GPU, one per HIP stream")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="cvx_set_option(NAME, VALUE) before the run (A/B experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-stage breakdown tomogram")
     ap.add_argument("--dry-run", action="store_true",
@@ -397,6 +398,9 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     _lib.load()
+    for kv in args.opt:
+        name, value = kv.split("=")
+        _lib.set_option(name, int(value))
 
     cfg = VIT_CONFIGS["dinov2_vitg14_reg"]
     vit = VitEngine(cfg, random_state_dict(cfg, seed=2, device=dev), dev)

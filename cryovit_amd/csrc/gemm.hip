@@ -596,6 +596,7 @@ int convt_small_dispatch(const cvx_gemm_desc& d, hipStream_t st);
 using namespace cvx;
 
 extern std::atomic<int> g_attn_variant, g_attn_xcd_remap;  // attention.hip
+extern std::atomic<int> g_ln_policy;                         // norm.hip
 
 extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
     CVX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvx::g_gemm256_dbg), sizeof(unsigned long long) * 32));
@@ -639,6 +640,10 @@ extern "C" int cvx_set_option(const char* name, int value) {
     }
     else if (!strcmp(name, "conv_wide")) g_conv_wide = value != 0;
     else if (!strcmp(name, "convt_small")) g_convt_small = value != 0;
+    else if (!strcmp(name, "ln_policy")) {
+        if (!one_of({0, 1, 2, 3})) return cvx_fail("set_option: ln_policy is a 2-bit mask (1: cacheable loads, 2: rows walked from the end)");
+        g_ln_policy = value;
+    }
     else if (!strcmp(name, "attn_variant")) {
         if (!one_of({0, 1, 3, 4, 5, 6}) && !(abl && one_of({10, 11, 12, 13})))
             return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");

@@ -21,6 +21,10 @@
 #pragma once
 #include "gemm256.h"
 
+#ifndef CVX_RESID_STORE_NT
+#define CVX_RESID_STORE_NT 1  // streaming stores for the fp32 residual stream (A/B: -DCVX_RESID_STORE_NT=0)
+#endif
+
 namespace cvx {
 
 constexpr bool DIRECT8 = true;  // SwiGLU epilogue: store straight from the accumulator layout (A/B switch for tools/)
@@ -322,7 +326,11 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                     if (FULL || (16 * u + 4 * i + mrow < mleft && nok)) {
                         float4 o;
                         o.x = xq4.x + d[i].x; o.y = xq4.y + d[i].y; o.z = xq4.z + d[i].z; o.w = xq4.w + d[i].w;
+#if CVX_RESID_STORE_NT
                         gst16_saddr_nt(xu, loff[i], __builtin_bit_cast(u32x4, o));
+#else
+                        gst16_saddr(xu, loff[i], __builtin_bit_cast(u32x4, o));
+#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

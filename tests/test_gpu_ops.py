@@ -206,6 +206,17 @@ def test_layernorm(gpu, C):
     ops.layernorm(x.to(gpu), w.to(gpu), b.to(gpu), out, rows, C, 1e-6)
     ref = F.layer_norm(x, (C,), w, b, 1e-6)
     assert torch.allclose(out.float().cpu(), ref, atol=2e-2, rtol=1e-2)
+    # the cache-policy / row-order variants of the wide-row kernel are the same arithmetic: bit-identical output
+    from cryovit_amd import _lib
+
+    try:
+        for pol in (0, 1, 2):
+            _lib.set_option("ln_policy", pol)
+            o2 = torch.zeros_like(out)
+            ops.layernorm(x.to(gpu), w.to(gpu), b.to(gpu), o2, rows, C, 1e-6)
+            assert torch.equal(o2, out), pol
+    finally:
+        _lib.set_option("ln_policy", 3)
 
 
 @pytest.fixture
