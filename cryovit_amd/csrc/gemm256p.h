@@ -21,6 +21,14 @@
 #pragma once
 #include "gemm256.h"
 
+#ifndef CVX_RESID_LOAD_NT
+#define CVX_RESID_LOAD_NT 1  // streaming loads of the fp32 residual stream in the epilogue (A/B: -DCVX_RESID_LOAD_NT=0)
+#endif
+#if CVX_RESID_LOAD_NT
+#define CVX_RESID_LOAD(p) ld_stream(p)
+#else
+#define CVX_RESID_LOAD(p) ([](const float* q) { const f32x4 v = *(const f32x4*)q; return float4{v[0], v[1], v[2], v[3]}; })(p)
+#endif
 #ifndef CVX_RESID_STORE_NT
 #define CVX_RESID_STORE_NT 1  // streaming stores for the fp32 residual stream (A/B: -DCVX_RESID_STORE_NT=0)
 #endif
@@ -296,7 +304,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                 const char* xu = (const char*)(xw + (long)(16 * u) * ldx);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    dst[i] = (Epi::ACCUM && (FULL || (16 * u + 4 * i + mrow < mleft && nok))) ? ld_stream((const float*)(xu + loff[i])) : float4{0.f, 0.f, 0.f, 0.f};
+                    dst[i] = (Epi::ACCUM && (FULL || (16 * u + 4 * i + mrow < mleft && nok))) ? CVX_RESID_LOAD((const float*)(xu + loff[i])) : float4{0.f, 0.f, 0.f, 0.f};
             };
             request(xv[0], 0);
             request(xv[1], 1);
