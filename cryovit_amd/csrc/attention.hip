@@ -96,11 +96,31 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
         koffs[jj] = (uint32_t)(srow * ldqk + schunk) * 2u;
         voffs[jj] = (uint32_t)(srow * kp + schunk) * 2u;
     }
+    // A query block whose rows all belong to wave 0 (1029 tokens = 8 x 128 + 5: every ninth block) runs as ONE wave: waves 1-3
+    // leave at once (a hardware barrier only counts the waves still alive) and wave 0 issues their DMA pieces too -- their wave
+    // slots go back to the CU instead of idling through 17 tiles of barriers.
+    const bool lone = VARIANT == 6 && qb * 128 + 32 >= ntok;  // (uniform per workgroup)
+    if (lone && wave != 0) return;
     auto issue = [&](int j, int buf) {
         const uint32_t kt = lds_addr(smem) + buf * 2 * ATT_TILE_BYTES + wave * 1024;
         const long kv0 = (long)j * KV_TILE;
         glds16_saddr2<ATT_THREADS * 16>(Kp + kv0 * ldqk, koffs[0], koffs[1], kt);
         glds16_saddr2<ATT_THREADS * 16>(Vp + kv0, voffs[0], voffs[1], kt + ATT_TILE_BYTES);
+        if (lone) {
+            // the pieces of the departed waves: wave w2's thread sits 8 w2 tile rows below this one, same chunk, and its swizzle
+            // term (row >> 1) & 7 differs by 4 w2 & 7, i.e. the 16-B chunk index flips bit 2 for odd w2 (ldqk and kp are multiples
+            // of 64 elements, so that bit is bit 6 of the byte offset).  Derived from opaque copies: hoisted out of the key loop, 12
+            // more offsets cost the common path a wave per SIMD.
+            uint32_t k0 = koffs[0], k1 = koffs[1], v0 = voffs[0], v1 = voffs[1];
+            asm volatile("" : "+v"(k0), "+v"(k1), "+v"(v0), "+v"(v1));
+#pragma unroll 1
+            for (int w2 = 1; w2 < 4; ++w2) {
+                const uint32_t fl = (w2 & 1) ? 64u : 0u;
+                const uint32_t dk = (uint32_t)(w2 * 16) * (uint32_t)ldqk, dv = (uint32_t)(w2 * 16) * (uint32_t)kp;
+                glds16_saddr2<ATT_THREADS * 16>(Kp + kv0 * ldqk, (k0 + dk) ^ fl, (k1 + dk) ^ fl, kt + w2 * 1024);
+                glds16_saddr2<ATT_THREADS * 16>(Vp + kv0, (v0 + dv) ^ fl, (v1 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
+            }
+        }
     };
 
     // fragment read offsets
