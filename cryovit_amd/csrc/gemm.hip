@@ -514,7 +514,8 @@ template <class E> struct epi_can_shift<E, std::void_t<decltype(std::declval<con
 // Tail split: a 256-tile grid whose last round would keep only a few CUs busy (e.g. 3096 tiles = 12 rounds + 24 tiles for
 // the N = 1536 GEMMs of one 128-slice batch) is cut into a main launch of whole rounds and a tail launch over the remaining
 // M rows with 128x128 tiles (4x as many, quarter-size tiles: the tail costs ~0.3 of a round instead of a full one).
-static std::atomic<int> g_tail_split{1};
+static std::atomic<int> g_tail_split{2};  // 2: also for the residual epilogue with a short K loop (proj), which pays off since the tail runs on 64 x 128 tiles
+static std::atomic<int> g_tail_tile{1};  // tail launches: 1 = 64 x 128 tiles (twice the workgroups on the idle chip), 0 = 128 x 128
 static long tail_split_rows(long M, long Npad, bool allow = true) {
     const long tiles_n = Npad / 256, tiles_m = (M + 255) / 256, tiles = tiles_n * tiles_m, rem = tiles % 256;
     if (!g_tail_split || !allow || tiles < 512 || rem == 0 || rem > 64) return M;
@@ -540,10 +541,13 @@ static int launch_256_split(const uint16_t* A, long lda, const uint16_t* Wt, lon
     if constexpr (epi_can_shift<Epi>::value) {
         // (the 128-tile kernel's fp32 read-modify-write epilogue is not LDS-staged: with a short K loop the tail would cost
         //  more than the idle round it removes -- measured on the proj GEMM)
-        const long m_main = tail_split_rows(M, Npad, !epi_has_preload<Epi>::value || Kpad >= 2048);
+        const long m_main = tail_split_rows(M, Npad, !epi_has_preload<Epi>::value || Kpad >= 2048 || g_tail_split == 2);
         if (m_main < M) {
             int rc = launch_256<Epi, false>(A, lda, Wt, ldw, m_main, Npad, Kpad, epi, st);
             if (rc) return rc;
+            // the tail is a handful of tiles on an otherwise idle chip: latency-bound, so more, smaller workgroups finish sooner
+            if (g_tail_tile)
+                return launch_nreg<TileCfg<64, 128, 1>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
             return launch_nreg<TileCfg<128, 128, 2>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
         }
     }
@@ -633,7 +637,11 @@ extern "C" int cvx_set_option(const char* name, int value) {
         if (value < 0 || value > 1000000) return cvx_fail("set_option: gemm_stagger is a cycle count in [0, 1e6]");
         g_gemm_stagger = value;  // persistent kernel: start offset between XCDs, cycles; the one-shot kernels: on / off
     }
-    else if (!strcmp(name, "gemm_tail_split")) g_tail_split = value != 0;
+    else if (!strcmp(name, "gemm_tail_split")) {
+        if (!one_of({0, 1, 2})) return cvx_fail("set_option: gemm_tail_split is 0 (off), 1 (on; residual epilogues only for K >= 2048) or 2 (always)");
+        g_tail_split = value;
+    }
+    else if (!strcmp(name, "gemm_tail_tile")) g_tail_tile = value != 0;
     else if (!strcmp(name, "conv_halo")) {
         if (!one_of({0, 1, 2})) return cvx_fail("set_option: conv_halo is 0 (implicit GEMM), 1 (tile halo) or 2 (z-marching ring)");
         g_conv_halo = value;
@@ -746,6 +754,16 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
                 const long m_main = tail_split_rows(d->m, d->n_pad);
                 int rc = launch_256<EpiVT, true>(A, d->lda, W, d->ldw, m_main, d->n_pad, d->k_pad, e, st);
                 if (rc || m_main == d->m) return rc;
+                if (g_tail_tile) {
+                    using CfgS = TileCfg<64, 128, 1>;
+                    const long m = d->m - m_main;
+                    const int tiles_n = (int)(d->n_pad / CfgS::BL), tiles_m = (int)((m + CfgS::BR - 1) / CfgS::BR);
+                    auto k = k_gemm_mreg<CfgS, EpiVT>;
+                    CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CfgS::LDS_BYTES));
+                    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), CfgS::LDS_BYTES, st, A + m_main * d->lda, d->lda, W, d->ldw,
+                                       (int)(d->k_pad / BK), tiles_n, tiles_m, e.shifted(m_main));
+                    return cvx_check_launch();
+                }
                 return tail128(A + m_main * d->lda, d->m - m_main, e.shifted(m_main));
             }
             return tail128(A, d->m, e);
