@@ -546,7 +546,7 @@ static int launch_256_split(const uint16_t* A, long lda, const uint16_t* Wt, lon
             int rc = launch_256<Epi, false>(A, lda, Wt, ldw, m_main, Npad, Kpad, epi, st);
             if (rc) return rc;
             // the tail is a handful of tiles on an otherwise idle chip: latency-bound, so more, smaller workgroups finish sooner
-            if (g_tail_tile)
+            if (g_tail_tile && (M - m_main) / 256 * (Npad / 256) * 8 <= 256)  // (8 small tiles per 256 x 256 tile: one round at most)
                 return launch_nreg<TileCfg<64, 128, 1>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
             return launch_nreg<TileCfg<128, 128, 2>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
         }
@@ -754,7 +754,7 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
                 const long m_main = tail_split_rows(d->m, d->n_pad);
                 int rc = launch_256<EpiVT, true>(A, d->lda, W, d->ldw, m_main, d->n_pad, d->k_pad, e, st);
                 if (rc || m_main == d->m) return rc;
-                if (g_tail_tile) {
+                if (g_tail_tile && (d->m - m_main) / 256 * (d->n_pad / 256) * 8 <= 256) {
                     using CfgS = TileCfg<64, 128, 1>;
                     const long m = d->m - m_main;
                     const int tiles_n = (int)(d->n_pad / CfgS::BL), tiles_m = (int)((m + CfgS::BR - 1) / CfgS::BR);
