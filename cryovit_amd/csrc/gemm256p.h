@@ -117,9 +117,14 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
     }
     long r0, l0;
     const uint16_t *Rc, *Lc, *Rn, *Ln;  // operand panels of the current / next tile
+    // group_l < 0: this workgroup's chunk of the sequence is walked from its END (the launch then finishes where the
+    // sequence starts; used for GEMMs whose activation operand was written front to back by the previous kernel, so its last
+    // rows are the ones still in the Infinity Cache)
+    const bool rev_walk = group_l < 0;
+    group_l = rev_walk ? -group_l : group_l;
     auto panels = [&](int pos, const uint16_t*& Rp, const uint16_t*& Lp, long& rr, long& ll) {
         int tr, tl;
-        tile_from_seq(c0 + pos, tiles_r, tiles_l, group_l, tr, tl);
+        tile_from_seq(c0 + (rev_walk ? cnt - 1 - pos : pos), tiles_r, tiles_l, group_l, tr, tl);
         rr = (long)tr * 256; ll = (long)tl * 256;
         Rp = Rmat + rr * ldr; Lp = Lmat + ll * ldl;
     };
