@@ -21,6 +21,9 @@
 #pragma once
 #include "gemm256.h"
 
+#ifndef CVX_BF16_STORE_NT
+#define CVX_BF16_STORE_NT 1  // streaming stores for the 16-wide bf16 epilogue (qk, fc1): A/B with -DCVX_BF16_STORE_NT=0
+#endif
 #ifndef CVX_RESID_LOAD_NT
 #define CVX_RESID_LOAD_NT 1  // streaming loads of the fp32 residual stream in the epilogue (A/B: -DCVX_RESID_LOAD_NT=0)
 #endif
@@ -409,7 +412,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                 for (int i = 0; i < 32 / RPI; ++i) {
                     const int row = RPI * i + srow;
                     if (FULL || (32 * q + row < mleft && ook)) {
-                        if constexpr (O16 == 16) gst16_saddr_nt(oq, loff[i], u32x4{d[i].x, d[i].y, d[i].z, d[i].w});
+                        if constexpr (O16 == 16 && CVX_BF16_STORE_NT) gst16_saddr_nt(oq, loff[i], u32x4{d[i].x, d[i].y, d[i].z, d[i].w});
                         else gst16_saddr(oq, loff[i], u32x4{d[i].x, d[i].y, d[i].z, d[i].w});  // 64-B segments: left to the L2's write combining
                     }
                 }
