@@ -131,6 +131,9 @@ template <bool ACC>
 struct EpiResidT {
     static constexpr bool ACCUM = ACC;
     float* x; long ldx; const float* bias; const float* gamma; long m_valid, n_valid;
+#ifdef CVX_LN_EMIT_PROTO
+    uint16_t* emit_xb = nullptr; long emit_ldb = 0;  // timing prototype (tools/bench_ln_emit.py): bf16 copy of the updated x
+#endif
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
     __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const {
@@ -140,7 +143,15 @@ struct EpiResidT {
     // the residual values are PRE-LOADED for a batch of output columns before any of them is stored: issued one after
     // the other, each load -> add -> store round trip exposed a full HBM latency (32 per lane per tile: the epilogue
     // took as long as the whole K loop of the proj GEMM -- tools/stamp_gemm_coarse.py)
-    EpiResidT shifted(long m_off) const { return EpiResidT{x + m_off * ldx, ldx, bias, gamma, m_valid - m_off, n_valid}; }
+    EpiResidT shifted(long m_off) const {
+        EpiResidT r = *this;
+        r.x = x + m_off * ldx;
+        r.m_valid = m_valid - m_off;
+#ifdef CVX_LN_EMIT_PROTO
+        if (r.emit_xb) r.emit_xb = emit_xb + m_off * emit_ldb;
+#endif
+        return r;
+    }
     static constexpr bool HAS_PRELOAD = true;
     template <int NV> struct Pre { float4 x[NV / 4]; };
     template <int NV>
@@ -608,6 +619,15 @@ extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
     CVX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvx::g_gemm256_dbg), sizeof(unsigned long long) * 32));
     return 0;
 }
+#ifdef CVX_LN_EMIT_PROTO
+static uint16_t* g_emit_xb_host = nullptr;
+static long g_emit_ldb_host = 0;
+extern "C" int cvx_debug_set_emit(void* xb, long ldb) {  // timing prototype only (tools/bench_ln_emit.py)
+    g_emit_xb_host = (uint16_t*)xb;
+    g_emit_ldb_host = ldb;
+    return 0;
+}
+#endif
 extern "C" int cvx_debug_read_gemm256p(unsigned long long* out96) {
     CVX_HIP(hipMemcpyFromSymbol(out96, HIP_SYMBOL(cvx::g_gemm256p_dbg), sizeof(unsigned long long) * 96));
     return 0;
@@ -730,6 +750,10 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         case CVX_EPI_RESID: {
             if (!d->out || !d->bias || !d->gamma) return cvx_fail("gemm: the residual epilogue needs out, bias and gamma (LayerScale)");
             EpiResid e{(float*)d->out, d->ldc, d->bias, d->gamma, d->m, d->n};
+#ifdef CVX_LN_EMIT_PROTO
+            if (!g_emit_xb_host) return cvx_fail("emit prototype: cvx_debug_set_emit first (the store counts of this build assume the emission)");
+            e.emit_xb = g_emit_xb_host; e.emit_ldb = g_emit_ldb_host;
+#endif
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_F32: {

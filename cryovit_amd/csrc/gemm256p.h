@@ -51,7 +51,11 @@ template <class E> struct epi_is_mreg<E, std::enable_if_t<E::MREG16>> : std::tru
 
 template <class Epi> constexpr int epi_stores_per_wave() {
     if constexpr (epi_is_mreg<Epi>::value) return 16;                            // 8 fragments x 2 stores of 8 rows
+#ifdef CVX_LN_EMIT_PROTO
+    else if constexpr (epi_has_preload<Epi>::value) return 48;                   // + 2 x 8 bf16 stores of the emission prototype
+#else
     else if constexpr (epi_has_preload<Epi>::value) return 32;                   // 4 x 8 float4 stores
+#endif
     else return 4 * (32 / (64 / (4 * Epi::OUT16 * 2 / 16)));                      // 4 x (32 rows / rows per instruction)
 }
 
@@ -74,6 +78,10 @@ __device__ __forceinline__ void tile_from_seq(int id, int tiles_r, int tiles_l, 
 // [wave>>2][tile][0..5] = K loop start, K loop end, epilogue start (after the un-stagger barrier), epilogue end, after the
 // post-epilogue barriers, end of the tile's first K tile
 __device__ unsigned long long g_gemm256p_dbg[2 * 8 * 6];
+#ifdef CVX_LN_EMIT_PROTO
+// timing prototype (tools/bench_ln_emit.py, never in the product library): the residual epilogue also emits bf16(x) -- what a
+// LayerNorm folded into the consuming GEMMs would need -- as 16-B stores after a lane-pair exchange
+#endif
 
 template <class Epi, bool FULL, bool DBG = false>
 __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat, long ldr, const uint16_t* __restrict__ Lmat, long ldl,
@@ -336,12 +344,18 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                 float4 d[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) d[i] = *(const float4*)(stg + (4 * i + mrow) * PITCH + ncol);
+#ifdef CVX_LN_EMIT_PROTO
+                uint2 pk[4];
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float4 xq4 = xv[u % 3][i];
                     if (FULL || (16 * u + 4 * i + mrow < mleft && nok)) {
                         float4 o;
                         o.x = xq4.x + d[i].x; o.y = xq4.y + d[i].y; o.z = xq4.z + d[i].z; o.w = xq4.w + d[i].w;
+#ifdef CVX_LN_EMIT_PROTO
+                        pk[i] = uint2{pack2bf(o.x, o.y), pack2bf(o.z, o.w)};
+#endif
 #if CVX_RESID_STORE_NT
                         gst16_saddr_nt(xu, loff[i], __builtin_bit_cast(u32x4, o));
 #else
@@ -349,6 +363,26 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
 #endif
                     }
                 }
+#ifdef CVX_LN_EMIT_PROTO
+                if (FULL && epi.emit_xb) {
+                    // lane pairs (even, odd column lane) exchange halves so each lane stores 8 consecutive columns of ONE row
+                    const bool odd = lane & 1;
+                    const long g_emit_ldb = epi.emit_ldb;
+                    const uintptr_t pb = (uintptr_t)(epi.emit_xb + (mw + 16 * u) * g_emit_ldb + nw);  // (wave-uniform: into SGPRs)
+                    char* bu = (char*)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                                       (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pb));
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {
+                        const uint2 keep = odd ? pk[2 * p2 + 1] : pk[2 * p2];
+                        const uint2 send = odd ? pk[2 * p2] : pk[2 * p2 + 1];
+                        const uint32_t r0 = __builtin_amdgcn_mov_dpp(send.x, 0xB1, 0xF, 0xF, true);
+                        const uint32_t r1 = __builtin_amdgcn_mov_dpp(send.y, 0xB1, 0xF, 0xF, true);
+                        const u32x4 v = odd ? u32x4{r0, r1, keep.x, keep.y} : u32x4{keep.x, keep.y, r0, r1};
+                        const uint32_t bo = ((uint32_t)(4 * (2 * p2 + (odd ? 1 : 0)) + mrow) * (uint32_t)g_emit_ldb + (uint32_t)(8 * ((lane & 15) >> 1))) * 2u;
+                        gst16_saddr(bu, bo, v);
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
