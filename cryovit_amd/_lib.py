@@ -123,6 +123,8 @@ SIGNATURES = {
     "cvx_dice_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p]),
     "cvx_dice_loss_forward": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "cvx_dice_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    "cvx_focal_loss_forward": (c_int, [c_void_p, c_void_p, c_long, c_float, c_void_p, c_void_p, c_void_p]),
+    "cvx_focal_loss_backward": (c_int, [c_void_p, c_void_p, c_long, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "cvx_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, C.c_double, C.c_double, C.c_double, C.c_double,
                                C.c_double, c_int, c_void_p]),
     "cvx_head_forward": (c_int, [C.POINTER(HeadDesc), C.POINTER(HeadWs), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -102,6 +102,77 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     }
 }
 
+
+// ---- Focal loss (models/losses.py:35-64 -> torchvision.ops.sigmoid_focal_loss, reduction "mean"): per element, x = the model output
+// the reference passes as "logits", t the label:  p = sigmoid(x), ce = max(x,0) - x t + log(1 + exp(-|x|)), p_t = p t + (1-p)(1-t),
+// loss = alpha_t (1 - p_t)^gamma ce with alpha_t = alpha t + (1-alpha)(1-t) and alpha = (n - sum t) / n over the labelled voxels
+// (losses.py:58: weight.item() -- a constant for the gradient).
+__device__ __forceinline__ void focal_terms(float x, float t, float alpha, float gamma, float& loss, float& dldx) {
+    const float p = 1.0f / (1.0f + __expf(-x));
+    const float ce = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+    const float pt = p * t + (1.0f - p) * (1.0f - t);
+    const float m = 1.0f - pt;
+    const float at = alpha * t + (1.0f - alpha) * (1.0f - t);
+    const float mg1 = gamma == 2.0f ? m : powf(fmaxf(m, 1e-30f), gamma - 1.0f);  // m^(gamma-1)
+    const float mg = mg1 * m;
+    loss = at * mg * ce;
+    const float dm = -(2.0f * t - 1.0f) * p * (1.0f - p);
+    dldx = at * (gamma * mg1 * dm * ce + mg * (p - t));
+}
+
+// mode 0: partials = (count, sum t, 0) over labels > -1;  mode 1: partials = (sum loss, 0, 0) with alpha from stats4
+__global__ __launch_bounds__(256) void k_focal_partials(const float* __restrict__ x, const int8_t* __restrict__ labels, long n, int mode,
+                                                        const float* __restrict__ stats4, float gamma, float* __restrict__ partials) {
+    __shared__ float red[2][4];
+    float a = 0.f, b = 0.f;
+    const float alpha = mode ? stats4[2] : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int lab = labels[i];
+        if (lab > -1) {
+            if (mode == 0) { a += 1.0f; b += (float)lab; }
+            else { float l, g; focal_terms(x[i], (float)lab, alpha, gamma, l, g); a += l; }
+        }
+    }
+    a = wave_sum(a); b = wave_sum(b);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = a; red[1][wave] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2) partials[(long)blockIdx.x * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x == 2) partials[(long)blockIdx.x * 3 + 2] = 0.f;
+}
+
+// mode 0: out4 = {count, sum t, alpha = (count - sum t) / count, -};  mode 1: out4[3] = sum loss / count
+__global__ __launch_bounds__(64) void k_focal_finalize(const float* __restrict__ partials, int nblk, int mode, float* __restrict__ out4) {
+    const int lane = threadIdx.x;
+    double s[2];
+    for (int k = 0; k < 2; ++k) {
+        double a = 0.0;
+        for (int b = lane; b < nblk; b += 64) a += (double)partials[(long)b * 3 + k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        s[k] = a;
+    }
+    if (lane == 0) {
+        if (mode == 0) {
+            const float cnt = (float)s[0], st = (float)s[1];
+            out4[0] = cnt; out4[1] = st; out4[2] = cnt > 0.f ? (cnt - st) / cnt : 0.f;
+        } else {
+            out4[3] = out4[0] > 0.f ? (float)s[0] / out4[0] : 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_focal_backward(const float* __restrict__ x, const int8_t* __restrict__ labels, long n,
+                                                        const float* __restrict__ stats4, float gamma, float gout, float* __restrict__ grad) {
+    const float alpha = stats4[2], scale = stats4[0] > 0.f ? gout / stats4[0] : 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int lab = labels[i];
+        float g = 0.f;
+        if (lab > -1) { float l; focal_terms(x[i], (float)lab, alpha, gamma, l, g); g *= scale; }
+        grad[i] = g;
+    }
+}
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -146,5 +217,28 @@ extern "C" int cvx_adamw_step(float* p, const float* g, float* m, float* v, long
     const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(k_adamw, dim3(stream_blocks(n, 2048)), dim3(256), 0, st, p, g, m, v, n, decay, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_focal_loss_forward(const float* x, const int8_t* labels, long n, float gamma, float* scratch, float* out4, hipStream_t st) {
+    if (!x || !labels || !scratch || !out4) return cvx_fail("focal_loss_forward: null pointer");
+    if (n < 0) return cvx_fail("focal_loss_forward: n < 0");
+    const unsigned nblk = stream_blocks(n, 2048);
+    for (int mode = 0; mode < 2; ++mode) {
+        hipLaunchKernelGGL(k_focal_partials, dim3(nblk), dim3(256), 0, st, x, labels, n, mode, out4, gamma, scratch);
+        int rc = cvx_check_launch();
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_focal_finalize, dim3(1), dim3(64), 0, st, scratch, (int)nblk, mode, out4);
+        rc = cvx_check_launch();
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int cvx_focal_loss_backward(const float* x, const int8_t* labels, long n, float gamma, const float* stats4, float grad_out,
+                                       float* grad, hipStream_t st) {
+    if (!x || !labels || !stats4 || !grad) return cvx_fail("focal_loss_backward: null pointer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_focal_backward, dim3(stream_blocks(n, 2048)), dim3(256), 0, st, x, labels, n, stats4, gamma, grad_out, grad);
     return cvx_check_launch();
 }

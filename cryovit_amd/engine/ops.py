@@ -244,6 +244,20 @@ def dice_loss_backward(probs, logits, labels: torch.Tensor, sums4: torch.Tensor,
          sums4.data_ptr(), float(grad_out), int(through_sigmoid), grad.data_ptr())
 
 
+def focal_loss_forward(x: torch.Tensor, labels: torch.Tensor, gamma: float, out4: torch.Tensor) -> None:
+    dev = _dev_check(x, labels, out4)
+    if x.dtype != torch.float32 or labels.dtype != torch.int8 or x.numel() != labels.numel() or out4.numel() < 4:
+        raise _lib.CvxError("focal_loss_forward: x fp32, labels int8 of the same size, out4 fp32[4]")
+    call(dev, "cvx_focal_loss_forward", _lib.load().cvx_focal_loss_forward, x.data_ptr(), labels.data_ptr(), x.numel(), float(gamma),
+         dice_scratch(x.device).data_ptr(), out4.data_ptr())
+
+
+def focal_loss_backward(x: torch.Tensor, labels: torch.Tensor, gamma: float, stats4: torch.Tensor, grad_out: float, grad: torch.Tensor) -> None:
+    dev = _dev_check(x, labels, stats4, grad)
+    call(dev, "cvx_focal_loss_backward", _lib.load().cvx_focal_loss_backward, x.data_ptr(), labels.data_ptr(), x.numel(), float(gamma),
+         stats4.data_ptr(), float(grad_out), grad.data_ptr())
+
+
 def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, *, lr: float, beta1: float, beta2: float,
                eps: float, weight_decay: float, step: int) -> None:
     dev = _dev_check(p, g, m, v)

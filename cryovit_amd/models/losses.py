@@ -59,3 +59,40 @@ def dice_loss_and_logit_grad(probs: Tensor, logits: Tensor | None, labels_i8: Te
     ops.dice_loss_backward(p, None if logits is None else logits.contiguous().view(-1), labels_i8.contiguous().view(-1), out4, grad_out,
                            grad, through_sigmoid=True)
     return out4[3], grad.view(probs.shape)
+
+
+class _FocalLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred: Tensor, labels_i8: Tensor, gamma: float) -> Tensor:
+        x = y_pred.detach().float().contiguous().view(-1)
+        out4 = torch.empty(4, dtype=torch.float32, device=x.device)
+        ops.focal_loss_forward(x, labels_i8, gamma, out4)
+        ctx.save_for_backward(x, labels_i8, out4)
+        ctx.shape, ctx.dtype, ctx.gamma = y_pred.shape, y_pred.dtype, gamma
+        return out4[3].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        x, labels_i8, out4 = ctx.saved_tensors
+        grad = torch.empty_like(x)
+        ops.focal_loss_backward(x, labels_i8, ctx.gamma, out4, float(grad_out), grad)
+        return grad.view(ctx.shape).to(ctx.dtype), None, None
+
+
+class FocalLoss(nn.Module):
+    """Focal loss (losses.py:35-64): ``torchvision.ops.sigmoid_focal_loss(y_pred, y_true, alpha=(n - sum y) / n, gamma, "mean")``.
+    Like the reference, the model output is handed to the formula as its "logits" (the reference passes probabilities there).
+    torchvision is not installed in the build image: the formula is restated from its published implementation
+    (``torchvision/ops/focal_loss.py``) -- parity unpinned against torchvision itself."""
+
+    def __init__(self, gamma=2, **kwargs) -> None:
+        super().__init__()
+        self.gamma = gamma
+        self.name = "FocalLoss"
+
+    def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+        if not y_pred.is_cuda:
+            raise ops._lib.CvxError("FocalLoss: predictions must live on a HIP device (no CPU fallback)")
+        if y_pred.numel() != y_true.numel():
+            raise ValueError(f"FocalLoss: {tuple(y_pred.shape)} predictions vs {tuple(y_true.shape)} labels")
+        return _FocalLossFn.apply(y_pred, y_true.detach().to(torch.int8).contiguous().view(-1), float(self.gamma))

@@ -213,6 +213,14 @@ int cvx_dice_loss_backward(const float* probs, const float* logits, const int8_t
                            int through_sigmoid, float* grad, hipStream_t stream);
 int cvx_adamw_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int step, hipStream_t stream);
+/* cvx_focal_loss_forward / _backward -- FocalLoss.forward (/root/reference/src/cryovit/models/losses.py:35-64), i.e.
+ * torchvision.ops.sigmoid_focal_loss(y_pred, y_true, alpha = (n - sum y) / n, gamma, reduction = "mean") over the voxels with
+ * label > -1 (x: the model output the reference passes as the loss's "logits"; labels int8).  out4 = {count, sum y, alpha, loss};
+ * scratch >= 3*CVX_DICE_BLOCKS floats.  backward: grad[i] = grad_out / count * d loss_i / d x_i, alpha treated as a constant
+ * (weight.item()), 0 where the label is -1. */
+int cvx_focal_loss_forward(const float* x, const int8_t* labels, long n, float gamma, float* scratch, float* out4, hipStream_t stream);
+int cvx_focal_loss_backward(const float* x, const int8_t* labels, long n, float gamma, const float* stats4, float grad_out, float* grad,
+                            hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Alternate encoder: SAM2.1 Hiera image encoder + FPN neck (BASELINE configs[4]).  These entry points, together with

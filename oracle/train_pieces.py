@@ -31,6 +31,29 @@ def masked_dice_loss(probs: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     return dice_loss(torch.masked_select(probs, mask).view(-1, 1), torch.masked_select(labels, mask).view(-1, 1).to(probs.dtype))
 
 
+def sigmoid_focal_loss(inputs: torch.Tensor, targets: torch.Tensor, alpha: float = 0.25, gamma: float = 2, reduction: str = "none") -> torch.Tensor:
+    """torchvision.ops.sigmoid_focal_loss (torchvision/ops/focal_loss.py, BSD-3; not installed here: restated from the published
+    implementation, parity unpinned against the package itself)."""
+    p = torch.sigmoid(inputs)
+    ce_loss = torch.nn.functional.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce_loss * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        alpha_t = alpha * targets + (1 - alpha) * (1 - targets)
+        loss = alpha_t * loss
+    if reduction == "mean":
+        loss = loss.mean()
+    elif reduction == "sum":
+        loss = loss.sum()
+    return loss
+
+
+def focal_loss(y_pred: torch.Tensor, y_true: torch.Tensor, gamma: float = 2) -> torch.Tensor:
+    """losses.py:56-64 on already masked tensors."""
+    weight = (y_true.numel() - y_true.sum()) / y_true.numel()
+    return sigmoid_focal_loss(y_pred, y_true, alpha=weight.item(), gamma=gamma, reduction="mean")
+
+
 def random_crop(data: dict, input_key: str) -> None:
     """tomo_dataset.py:148-178, in place; draws from the global ``np.random`` state like the reference."""
     max_depth = 128

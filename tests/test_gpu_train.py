@@ -114,3 +114,28 @@ def test_optimisation_loop_dice_plus_adamw(gpu):
     assert lg[-1] < lg[0] - 0.05
     assert torch.allclose(w_gpu[0].detach().cpu(), w_cpu[0].detach(), atol=2e-3)
     assert w_gpu[0].data_ptr() == opt_g.flat_p.data_ptr()  # the parameter IS a view of the flat buffer
+
+
+@pytest.mark.parametrize("gamma", [2, 1.5])
+def test_focal_loss_against_oracle(gpu, gamma):
+    """FocalLoss (losses.py:35-64) against the oracle restatement of torchvision's sigmoid_focal_loss (float64): value and autograd
+    gradient, masked in the kernel; alpha = (n - sum y) / n is a constant of the gradient like the reference's weight.item()."""
+    from cryovit_amd.models.losses import FocalLoss
+    from oracle import train_pieces as tp
+
+    gen = torch.Generator().manual_seed(31)
+    n = 50021
+    x = torch.rand(n, generator=gen)            # the reference feeds probabilities
+    x[:100] = torch.randn(100, generator=gen) * 4  # ... and the formula must hold for any real input
+    labels = torch.randint(-1, 2, (n,), generator=gen)
+    m = labels > -1
+    xr = x.double().clone().requires_grad_(True)
+    ref = tp.focal_loss(xr[m], labels[m].double(), gamma=gamma)
+    ref.backward()
+    xg = x.to(gpu).requires_grad_(True)
+    loss = FocalLoss(gamma=gamma)(xg, labels.to(gpu))
+    assert abs(float(loss.detach()) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    (2.0 * loss).backward()
+    want = 2.0 * xr.grad.float()
+    assert torch.allclose(xg.grad.cpu(), want, rtol=2e-4, atol=1e-9 + 2e-6 * float(want.abs().max()))
+    assert torch.all(xg.grad[labels.to(gpu) < 0] == 0)
