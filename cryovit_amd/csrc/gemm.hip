@@ -425,6 +425,7 @@ __global__ __launch_bounds__(G256_THREADS) void k_gemm256p_mreg(const uint16_t* 
 }
 
 // tuning switches (cvx_set_option): A/B the tile kernels and pipeline schedules inside ONE process
+static std::atomic<int> g_resid_stagger{0};  // cycles between the XCDs' start offsets in the residual GEMMs ("gemm_resid_stagger")
 static std::atomic<int> g_resid_reverse{0};  // residual GEMMs walk their tile sequence from the end (A/B: "gemm_resid_reverse")
 static std::atomic<int> g_tile_group_l_host{8};  // host copy of g_tile_group_l (the persistent kernel takes it as an argument)
 static std::atomic<int> g_use_gemm256{1}, g_gemm256_variant{9}, g_gemm_stagger{0};  // 9 = persistent (gemm256p.h)  // stagger: measured no gain (tools/bench_gemm.py 5 vs 1005)
@@ -487,7 +488,7 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             CVX_HIP(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS_BYTES));
             hipLaunchKernelGGL(kp, dim3(grid), dim3(G256_THREADS), G256P_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / BK), tiles_n, tiles_m,
                                (epi_has_preload<Epi>::value && g_resid_reverse ? -1 : 1) * (int)g_tile_group_l_host,
-                               ntiles > grid ? (int)g_gemm_stagger : 0, epi);
+                               ntiles > grid ? (epi_has_preload<Epi>::value ? (int)g_resid_stagger : (int)g_gemm_stagger) : 0, epi);
             return cvx_check_launch();
         }
     }
@@ -665,6 +666,10 @@ extern "C" int cvx_set_option(const char* name, int value) {
     }
     else if (!strcmp(name, "gemm_tail_tile")) g_tail_tile = value != 0;
     else if (!strcmp(name, "gemm_resid_reverse")) g_resid_reverse = value != 0;
+    else if (!strcmp(name, "gemm_resid_stagger")) {
+        if (value < 0 || value > 1000000) return cvx_fail("set_option: gemm_resid_stagger is a cycle count in [0, 1e6]");
+        g_resid_stagger = value;
+    }
     else if (!strcmp(name, "conv_halo")) {
         if (!one_of({0, 1, 2})) return cvx_fail("set_option: conv_halo is 0 (implicit GEMM), 1 (tile halo) or 2 (z-marching ring)");
         g_conv_halo = value;
