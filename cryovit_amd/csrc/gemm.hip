@@ -133,6 +133,7 @@ struct EpiResidT {
     float* x; long ldx; const float* bias; const float* gamma; long m_valid, n_valid;
 #ifdef CVX_LN_EMIT_PROTO
     uint16_t* emit_xb = nullptr; long emit_ldb = 0;  // timing prototype (tools/bench_ln_emit.py): bf16 copy of the updated x
+    float* emit_part = nullptr; long emit_rows = 0;  // ... and row partial sums P[4 * N tiles][emit_rows][2]
 #endif
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
@@ -149,6 +150,7 @@ struct EpiResidT {
         r.m_valid = m_valid - m_off;
 #ifdef CVX_LN_EMIT_PROTO
         if (r.emit_xb) r.emit_xb = emit_xb + m_off * emit_ldb;
+        if (r.emit_part) r.emit_part = emit_part + m_off * 2;
 #endif
         return r;
     }
@@ -623,9 +625,13 @@ extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
 #ifdef CVX_LN_EMIT_PROTO
 static uint16_t* g_emit_xb_host = nullptr;
 static long g_emit_ldb_host = 0;
-extern "C" int cvx_debug_set_emit(void* xb, long ldb) {  // timing prototype only (tools/bench_ln_emit.py)
+static float* g_emit_part_host = nullptr;
+static long g_emit_rows_host = 0;
+extern "C" int cvx_debug_set_emit(void* xb, long ldb, float* part, long rows) {  // timing prototype only (tools/bench_ln_emit.py)
     g_emit_xb_host = (uint16_t*)xb;
     g_emit_ldb_host = ldb;
+    g_emit_part_host = part;
+    g_emit_rows_host = rows;
     return 0;
 }
 #endif
@@ -758,6 +764,8 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
 #ifdef CVX_LN_EMIT_PROTO
             if (!g_emit_xb_host) return cvx_fail("emit prototype: cvx_debug_set_emit first (the store counts of this build assume the emission)");
             e.emit_xb = g_emit_xb_host; e.emit_ldb = g_emit_ldb_host;
+            if (!g_emit_part_host) return cvx_fail("emit prototype: the partial-sum buffer is required too");
+            e.emit_part = g_emit_part_host; e.emit_rows = g_emit_rows_host;
 #endif
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }

@@ -52,7 +52,7 @@ template <class E> struct epi_is_mreg<E, std::enable_if_t<E::MREG16>> : std::tru
 template <class Epi> constexpr int epi_stores_per_wave() {
     if constexpr (epi_is_mreg<Epi>::value) return 16;                            // 8 fragments x 2 stores of 8 rows
 #ifdef CVX_LN_EMIT_PROTO
-    else if constexpr (epi_has_preload<Epi>::value) return 48;                   // + 2 x 8 bf16 stores of the emission prototype
+    else if constexpr (epi_has_preload<Epi>::value) return 49;                   // + 2 x 8 bf16 stores + 1 row-statistics store (prototype)
 #else
     else if constexpr (epi_has_preload<Epi>::value) return 32;                   // 4 x 8 float4 stores
 #endif
@@ -355,6 +355,19 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                         o.x = xq4.x + d[i].x; o.y = xq4.y + d[i].y; o.z = xq4.z + d[i].z; o.w = xq4.w + d[i].w;
 #ifdef CVX_LN_EMIT_PROTO
                         pk[i] = uint2{pack2bf(o.x, o.y), pack2bf(o.z, o.w)};
+                        if constexpr (FULL) {   // row partial sums of these 64 columns: in-lane, then across the 16 lanes that share the row (DPP)
+                            float rs = (o.x + o.y) + (o.z + o.w), rq = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0xB1, 0xF, 0xF, true));
+                            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0xB1, 0xF, 0xF, true));
+                            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x4E, 0xF, 0xF, true));
+                            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x4E, 0xF, 0xF, true));
+                            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x141, 0xF, 0xF, true));
+                            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x141, 0xF, 0xF, true));
+                            rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x140, 0xF, 0xF, true));
+                            rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x140, 0xF, 0xF, true));
+                            // (bias / gamma left the constants buffer at the top of the epilogue: it stages the 128 rows' statistics)
+                            if ((lane & 15) == 0) *(float2*)(cbuf + (16 * u + 4 * i + mrow) * 8) = float2{rs, rq};
+                        }
 #endif
 #if CVX_RESID_STORE_NT
                         gst16_saddr_nt(xu, loff[i], __builtin_bit_cast(u32x4, o));
@@ -385,6 +398,18 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifdef CVX_LN_EMIT_PROTO
+            if (FULL && epi.emit_part) {
+                // P[slot = 4 * (N tile) + wr][row][2]: the wave's 128 rows x (sum, sum of squares) are 1 KiB = one store
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const f32x4 st4 = *(const f32x4*)(cbuf + lane * 16);
+                const long slot = (r0 >> 8) * 4 + wr;
+                const uintptr_t pp = (uintptr_t)(epi.emit_part + (slot * epi.emit_rows + mw) * 2);
+                char* pbase = (char*)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
+                                      (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pp));
+                gst16_saddr(pbase, (uint32_t)lane * 16u, __builtin_bit_cast(u32x4, st4));
+            }
+#endif
         } else {
             constexpr int O16 = Epi::OUT16, ROWB = 4 * O16 * 2, PITCHB = ROWB + 16, LPR = ROWB / 16, RPI = 64 / LPR;
             static_assert(32 * PITCHB <= 6144, "staging buffer of a wave");
