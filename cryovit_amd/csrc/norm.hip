@@ -60,6 +60,55 @@ __global__ __launch_bounds__(256) void k_layernorm_bf16_v4(const float* __restri
 }
 
 
+// Narrower still (C <= 384: Hiera stages 1 and 2 with 144 / 288 channels): at one row per wave only 36 / 72 of the 64 / 128 lane slots
+// carry data.  Here a row takes LPR = 16 / 32 lanes, a wave 4 / 2 rows, a lane NJ float4s (lane-strided): 75 % of the slots, and
+// four / two rows' loads in flight per wave.  Reductions stay inside the LPR-lane group (xor butterflies below LPR).
+template <int LPR, int NJ>
+__global__ __launch_bounds__(256) void k_layernorm_bf16_rows(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                             const float* __restrict__ b, uint16_t* __restrict__ out, long ldo,
+                                                             long rows, int C, float eps) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
+    const long rr = live ? row : rows - 1;  // (the clamped duplicate is computed and not stored: keeps the shuffles convergent)
+    const int C4 = C >> 2;
+    float4 v[NJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = sub + LPR * j;
+        v[j] = i < C4 ? *(const float4*)(x + rr * ldx + 4 * i) : float4{0.f, 0.f, 0.f, 0.f};
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (sub + LPR * j < C4) {
+            const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int i = sub + LPR * j;
+        if (i < C4) {
+            const float4 ww = *(const float4*)(w + 4 * i), bb = *(const float4*)(b + 4 * i);
+            uint2 o2;
+            o2.x = pack2bf((v[j].x - mean) * rstd * ww.x + bb.x, (v[j].y - mean) * rstd * ww.y + bb.y);
+            o2.y = pack2bf((v[j].z - mean) * rstd * ww.z + bb.z, (v[j].w - mean) * rstd * ww.w + bb.w);
+            *(uint2*)(out + row * ldo + 4 * i) = o2;
+        }
+    }
+}
+
 // LN_V8: 8 consecutive channels per lane and step (two adjacent 16-B loads, ONE 16-B store of 8 bf16) -- full-width stores
 // instead of the 8-B ones of the float4 mapping; LN_ROWS rows per wave keep twice the loads in flight.
 constexpr int LN_MAXJ8 = 4;   // 8-channel chunks per lane: C <= 64*8*4 = 2048
@@ -377,6 +426,16 @@ extern "C" int cvx_layernorm_bf16(const float* x, long ldx, const float* w, cons
                                   long rows, int C, float eps, hipStream_t st) {
     if (rows <= 0) return 0;
     if (C % 4 || C > 2048 || ldx % 4 || ldo % 4) return cvx_fail("layernorm: C%4==0, C<=2048, ld%4==0 required");
+    if (C <= 192) {  // 16 lanes per row, 4 rows per wave
+        hipLaunchKernelGGL((k_layernorm_bf16_rows<16, 3>), dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, x, ldx, w, b, (uint16_t*)out, ldo, rows,
+                           C, eps);
+        return cvx_check_launch();
+    }
+    if (C <= 384) {  // 32 lanes per row, 2 rows per wave
+        hipLaunchKernelGGL((k_layernorm_bf16_rows<32, 3>), dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, st, x, ldx, w, b, (uint16_t*)out, ldo, rows,
+                           C, eps);
+        return cvx_check_launch();
+    }
     if (C < 1024 || C % 8 || ldo % 8) {
         hipLaunchKernelGGL(k_layernorm_bf16_v4, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, w, b, (uint16_t*)out, ldo, rows, C,
                            eps);

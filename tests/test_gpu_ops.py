@@ -195,7 +195,7 @@ def test_gemm_vt(gpu):
     assert torch.all(got[..., ntp:] == 0)
 
 
-@pytest.mark.parametrize("C", [128, 384, 1536])
+@pytest.mark.parametrize("C", [128, 144, 288, 384, 576, 1152, 1536])
 def test_layernorm(gpu, C):
     from cryovit_amd.engine import ops
 
