@@ -10,6 +10,7 @@
 #include "common.h"
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
+#include <atomic>
 
 namespace cvx {
 
@@ -65,7 +66,10 @@ __global__ __launch_bounds__(256) void k_sam_patches(const void* __restrict__ sr
 // The accumulator layout of S^T (lane: q = lane%16, keys 4g..4g+3) IS the B-operand layout of P^T: probabilities go
 // from the softmax to the second product without leaving the lane.  Online softmax over key tiles of 64.
 // ---------------------------------------------------------------------------------------------------
-template <int DSTEPS>
+// PF (256-thread blocks, head_dim % 8 == 0, power-of-two window, 16-B aligned rows): the K / V tile of the NEXT 64 keys is fetched into
+// registers while the current one is consumed and written to LDS after the barrier (16-B pieces, row / column of every piece
+// computed once) -- the plain form stages each tile synchronously with 8-B pieces and two divisions per piece.
+template <int DSTEPS, bool PF = false>
 __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restrict__ q, long ldq, const uint16_t* __restrict__ k,
                                                        const uint16_t* __restrict__ v, long ldkv, uint16_t* __restrict__ out,
                                                        long ldo, int hd, int heads, int G, int ws, int Gq, int wsq,
@@ -107,9 +111,46 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
     float m = -INFINITY, l = 0.f;
 
     const int chunks = hd >> 2;  // 8-byte pieces per row
+    // PF: this thread's (at most three) 16-B pieces of a tile: tile row, column, LDS offset -- the same for every tile
+    constexpr int NPF = 3;
+    [[maybe_unused]] int prow[NPF], pcol[NPF];
+    [[maybe_unused]] uint4 rk[NPF], rv[NPF];
+    [[maybe_unused]] const int wsh = 31 - __builtin_clz(ws);
+    if constexpr (PF) {
+        const int ch16 = hd >> 3;
+#pragma unroll
+        for (int pp = 0; pp < NPF; ++pp) {
+            const int i = tid + 256 * pp;
+            prow[pp] = i < 64 * ch16 ? i / ch16 : -1;
+            pcol[pp] = i < 64 * ch16 ? (i % ch16) * 8 : 0;
+            rk[pp] = uint4{0u, 0u, 0u, 0u};
+            rv[pp] = uint4{0u, 0u, 0u, 0u};
+        }
+    }
+    [[maybe_unused]] auto prefetch = [&](int k0) {
+        const int nkt = min(64, nk - k0);
+#pragma unroll
+        for (int pp = 0; pp < NPF; ++pp) {
+            // (unconditional loads from a clamped row: a conditional assignment sent the staging registers to scratch)
+            const int kl = k0 + ((prow[pp] >= 0 && prow[pp] < nkt) ? prow[pp] : 0);
+            const long krow = d * G * G + (long)(wy * ws + (kl >> wsh)) * G + wx * ws + (kl & (ws - 1));
+            rk[pp] = *(const uint4*)(k + krow * ldkv + (long)head * hd + pcol[pp]);
+            rv[pp] = *(const uint4*)(v + krow * ldkv + (long)head * hd + pcol[pp]);
+        }
+    };
+    if constexpr (PF) prefetch(0);
     for (int k0 = 0; k0 < nk; k0 += 64) {
         const int nkt = min(64, nk - k0), nsub = nkt >> 4;
         __syncthreads();  // previous tile fully consumed (also orders the pad zeroing before the first reads)
+        if constexpr (PF) {
+#pragma unroll
+            for (int pp = 0; pp < NPF; ++pp) {
+                if (prow[pp] >= 0 && prow[pp] < nkt) {
+                    *(uint4*)(Ks + prow[pp] * LDR + pcol[pp]) = rk[pp];
+                    *(uint4*)(Vs + prow[pp] * LDR + pcol[pp]) = rv[pp];
+                }
+            }
+        } else {
         for (int i = tid; i < nkt * chunks; i += nthreads) {
             const int r = i / chunks, c = (i % chunks) * 4;
             const int kl = k0 + r;
@@ -117,7 +158,11 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
             *(uint2*)(Ks + r * LDR + c) = *(const uint2*)(k + krow * ldkv + (long)head * hd + c);
             *(uint2*)(Vs + r * LDR + c) = *(const uint2*)(v + krow * ldkv + (long)head * hd + c);
         }
+        }
         __syncthreads();
+        if constexpr (PF) {
+            if (k0 + 64 < nk) prefetch(k0 + 64);  // in flight while this tile is consumed
+        }
 
         f32x4 sacc[4];
 #pragma unroll
@@ -287,6 +332,8 @@ __global__ __launch_bounds__(256) void k_fpn_out(const float* __restrict__ lat, 
 
 using namespace cvx;
 
+std::atomic<int> g_win_attn_prefetch{1};  // cvx_set_option("win_attn_prefetch", 0 / 1) -- gemm.hip
+
 extern "C" int cvx_sam_patches(const void* src, int mode, int D, int H, int W, int S, void* out, long ldo, hipStream_t st) {
     if (D <= 0) return 0;
     if (mode < 0 || mode > 2 || S <= 0 || S % 4 || ldo < 147 || H <= 0 || W <= 0) return cvx_fail("sam_patches: bad arguments");
@@ -312,15 +359,20 @@ extern "C" int cvx_window_attention_bf16(const void* q, long ldq, const void* k,
     const dim3 blocks((nq + 63) / 64, nwin * heads, slices);
     const dim3 threads(64 * (nq >= 64 ? 4 : (nq + 15) / 16));
     const uint16_t *qq = (const uint16_t*)q, *kk = (const uint16_t*)k, *vv = (const uint16_t*)v;
-    if (head_dim <= 64)
-        hipLaunchKernelGGL(k_win_attention<4>, blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, head_dim, heads,
-                           grid, window, q_grid, q_window, scale_log2e);
-    else if (head_dim <= 80)
-        hipLaunchKernelGGL(k_win_attention<5>, blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, head_dim, heads,
-                           grid, window, q_grid, q_window, scale_log2e);
-    else
-        hipLaunchKernelGGL(k_win_attention<6>, blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, head_dim, heads,
-                           grid, window, q_grid, q_window, scale_log2e);
+    // register-prefetch form: full 256-thread blocks, 16-B pieces (head_dim % 8, row starts 16-B aligned), power-of-two window
+    const bool pf = g_win_attn_prefetch && threads.x == 256 && head_dim % 8 == 0 && ldkv % 8 == 0 && (window & (window - 1)) == 0 &&
+                    ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
+#define CVX_WIN_LAUNCH(DS)                                                                                                          \
+    do {                                                                                                                            \
+        if (pf) hipLaunchKernelGGL((k_win_attention<DS, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
+                                   head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                   \
+        else hipLaunchKernelGGL((k_win_attention<DS, false>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo,    \
+                                head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                      \
+    } while (0)
+    if (head_dim <= 64) CVX_WIN_LAUNCH(4);
+    else if (head_dim <= 80) CVX_WIN_LAUNCH(5);
+    else CVX_WIN_LAUNCH(6);
+#undef CVX_WIN_LAUNCH
     return cvx_check_launch();
 }
 
