@@ -151,12 +151,29 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
                 }
             }
         } else {
-        for (int i = tid; i < nkt * chunks; i += nthreads) {
-            const int r = i / chunks, c = (i % chunks) * 4;
-            const int kl = k0 + r;
-            const long krow = d * G * G + (long)(wy * ws + kl / ws) * G + wx * ws + kl % ws;
-            *(uint2*)(Ks + r * LDR + c) = *(const uint2*)(k + krow * ldkv + (long)head * hd + c);
-            *(uint2*)(Vs + r * LDR + c) = *(const uint2*)(v + krow * ldkv + (long)head * hd + c);
+        // four pieces of K and of V are loaded before any of them is stored: one load -> store pair per iteration made every
+        // iteration wait for its own HBM round trip (the 64-thread blocks of the last stage spent 18 of them per tile)
+        for (int i0 = tid; i0 < nkt * chunks; i0 += 4 * nthreads) {
+            uint2 tk[4], tv[4];
+            int off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * nthreads;
+                const int ic = i < nkt * chunks ? i : i0;  // (clamped duplicate, not stored)
+                const int r = ic / chunks, c = (ic % chunks) * 4;
+                const int kl = k0 + r;
+                const long krow = d * G * G + (long)(wy * ws + kl / ws) * G + wx * ws + kl % ws;
+                tk[u] = *(const uint2*)(k + krow * ldkv + (long)head * hd + c);
+                tv[u] = *(const uint2*)(v + krow * ldkv + (long)head * hd + c);
+                off[u] = i < nkt * chunks ? r * LDR + c : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (off[u] >= 0) {
+                    *(uint2*)(Ks + off[u]) = tk[u];
+                    *(uint2*)(Vs + off[u]) = tv[u];
+                }
+            }
         }
         }
         __syncthreads();
