@@ -35,13 +35,26 @@ __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ 
         const int ty = (int)(t2 % tiles_y), z = (int)(t2 / tiles_y);
         const int x0 = tx * CO_TX - 1, y0 = ty * CO_TY - 1;
         __syncthreads();  // the previous tile's reads are done (also orders the weight copy before the first use)
-        for (int i = threadIdx.x; i < 3 * CO_HY * CO_HX; i += 256) {
-            const int hx = i % CO_HX, hy = (i / CO_HX) % CO_HY, hz = i / (CO_HX * CO_HY);
-            const int xx = x0 + hx, yy = y0 + hy, zz = z + hz - 1;
-            uint4 u = uint4{0u, 0u, 0u, 0u};  // "same" padding: zeros outside the volume
-            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D)
-                u = *(const uint4*)(in + (((long)zz * H + yy) * W + xx) * 8);
-            halo[hz][hy][hx] = u;
+        // all of a thread's (at most five) halo voxels are loaded before the first is stored: load -> store pairs in a loop made
+        // each iteration wait for its own round trip
+        {
+            constexpr int NH = 3 * CO_HY * CO_HX, NIT = (NH + 255) / 256;
+            uint4 hu[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                const int ic = i < NH ? i : 0;
+                const int hx = ic % CO_HX, hy = (ic / CO_HX) % CO_HY, hz = ic / (CO_HX * CO_HY);
+                const int xx = x0 + hx, yy = y0 + hy, zz = z + hz - 1;
+                hu[it] = uint4{0u, 0u, 0u, 0u};  // "same" padding: zeros outside the volume
+                if (i < NH && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D)
+                    hu[it] = *(const uint4*)(in + (((long)zz * H + yy) * W + xx) * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = threadIdx.x + 256 * it;
+                if (i < NH) ((uint4*)halo)[i] = hu[it];
+            }
         }
         __syncthreads();
         const int x = tx * CO_TX + lx, y = ty * CO_TY + ly;
