@@ -14,6 +14,7 @@ from torch import Tensor, nn
 
 from cryovit_amd.engine import ops
 from cryovit_amd.engine.head import REF_WIDTHS, HeadEngine
+from cryovit_amd.models.base import EvalProtocol
 from cryovit_amd.models.metrics import dice_from_sums
 
 
@@ -42,7 +43,7 @@ class SynthesisBlock(nn.Module):
         )
 
 
-class CryoVIT(nn.Module):
+class CryoVIT(EvalProtocol, nn.Module):
     def __init__(self, input_key: str = "dino_features", lr: float = 1e-3, weight_decay: float = 1e-3, losses=None, metrics=None,
                  name: str = "CryoVIT", custom_kwargs=None, device="cuda:0", **kwargs) -> None:
         super().__init__()
@@ -108,46 +109,6 @@ class CryoVIT(nn.Module):
             cl[: D * h * w] = xb.to(self._device).permute(0, 2, 3, 1).reshape(-1, C).to(torch.float16)
             outs.append(self.engine().forward(cl, D, h, w, want_probs=False, mask_threshold=threshold)["mask"])
         return outs
-
-    # ---- evaluation protocol (base_model.py:91-112, 176-241) -------------------------------------------------------------
-    @torch.inference_mode()
-    def _masked_predict(self, batch, use_mito_mask: bool = False) -> dict[str, Tensor]:
-        """Predictions and labels restricted to labelled voxels (``labels > -1``), optionally also to the ``labels/mito``
-        mask of the batch's aux data; everything stays on the device."""
-        y_true = batch.labels.to(self._device)
-        y_pred_full = self.forward(batch)  # (B, D, H, W) probabilities
-        mask = y_true > -1.0
-        if use_mito_mask:
-            assert batch.aux_data is not None and "labels/mito" in batch.aux_data, "Batch aux_data must contain 'labels/mito' key for mito masking."
-            mask = mask & (torch.as_tensor(batch.aux_data["labels/mito"][0]).to(self._device) > 0)  # eval batch size is 1
-        return {"preds": torch.masked_select(y_pred_full, mask).view(-1, 1), "labels": torch.masked_select(y_true, mask).view(-1, 1),
-                "preds_full": y_pred_full}
-
-    @torch.inference_mode()
-    def test_step(self, batch, batch_idx: int = 0):
-        """One evaluation batch -> ``BatchedModelResult`` (base_model.py:176-241): predictions, per-tomogram metrics (each
-        metric is called once, then reset: a per-batch value), file metadata for the writers.  Losses are training-side
-        (SURVEY s.8f N4) and are computed only if ``losses`` holds callables."""
-        from cryovit_amd.types import BatchedModelResult
-
-        assert batch.aux_data is not None and "data" in batch.aux_data, "Batch aux_data must contain 'data' key for testing."
-        use_mito_mask = bool("labels/mito" in batch.aux_data and len(batch.aux_data["labels/mito"]))
-        out = self._masked_predict(batch, use_mito_mask=use_mito_mask)
-        y_pred, y_true, y_pred_full = out["preds"], out["labels"], out["preds_full"]
-        samples, tomo_names = batch.metadata.identifiers
-        split_id = batch.metadata.split_id
-        metrics = {}
-        for name, m_fn in self.metric_fns.items():
-            metrics[name] = float(m_fn(y_pred, y_true))
-            m_fn.reset()
-        losses = {k: float(fn(y_pred, y_true)) for k, fn in self.loss_fns.items()}
-        if losses:
-            losses["total"] = sum(losses.values())
-        return BatchedModelResult(
-            num_tomos=batch.num_tomos, samples=samples, tomo_names=tomo_names,
-            split_id=None if split_id is None else [int(s) for s in split_id],
-            data=batch.aux_data["data"], label=[t.cpu().numpy() for t in batch.labels],
-            preds=[t.float().cpu().numpy() for t in y_pred_full], losses=losses, metrics=metrics, aux_data=None)
 
     @torch.inference_mode()
     def predict_with_dice(self, feats_cl: Tensor, D: int, h: int, w: int, labels: Tensor | None):

@@ -8,6 +8,7 @@ import torch
 from torch import Tensor, nn
 
 from cryovit_amd.engine.unet3d import UNet3DEngine
+from cryovit_amd.models.base import EvalProtocol
 from cryovit_amd.models.cryovit import _Params, _Slot
 
 REF_WIDTHS = ((16, 64, 256), 384)
@@ -41,7 +42,7 @@ class SynthesisBlock(nn.Module):
         self.layers = nn.Sequential(_Proj(cout + cskip, cout), _norm(cout), _Slot(), _k3(cout, cout), _norm(cout), _Slot())
 
 
-class UNet3D(nn.Module):
+class UNet3D(EvalProtocol, nn.Module):
     def __init__(self, input_key: str = "data", lr: float = 1e-3, weight_decay: float = 1e-3, losses=None, metrics=None, name: str = "UNet3D",
                  custom_kwargs=None, device="cuda:0", widths=REF_WIDTHS, **kwargs) -> None:
         super().__init__()

@@ -140,3 +140,38 @@ def test_unet3d_reference_widths_runs_and_matches_oracle(gpu):
     print(f"unet3d ref widths: logit err max {float(lerr.max()):.2e} mean {float(lerr.mean()):.2e}")
     assert float(lerr.max()) <= 2e-1 and float(lerr.mean()) <= 8e-3
     assert torch.allclose(probs.cpu(), torch.sigmoid(lg.cpu()), atol=1e-6)
+
+
+def test_unet3d_evaluation_protocol(gpu, gold):
+    """``test_step`` / ``validation_step`` of the shared evaluation protocol (base_model.py:91-112, 153-165, 176-241) on the UNet3D
+    mirror: TomogramData -> collate_fn -> masked prediction -> DiceLoss + DiceMetric, against the same quantities computed from the
+    reference-pinned fixture's probabilities on the CPU."""
+    from cryovit_amd.datasets import collate_fn
+    from cryovit_amd.models import DiceLoss, DiceMetric, UNet3D
+    from cryovit_amd.models.metrics import dice_from_sums
+    from cryovit_amd.types import TomogramData
+    from oracle import train_pieces as tp
+    from oracle import unet3d as ou
+
+    g = gold("unet3d_narrow.npz")
+    orc = ou.UNet3D(ou.NARROW_WIDTHS)
+    ou.rescaled_init_(orc, seed=int(g["seed"]))
+    model = UNet3D(device=gpu, widths=ou.NARROW_WIDTHS, losses={"dice_loss": DiceLoss()}, metrics={"dice_metric": DiceMetric()})
+    model.load_state_dict(orc.state_dict(), strict=True)
+    vol = torch.from_numpy(g["vol"])[0, :, 0]  # [D, H, W]
+    D, H, W = vol.shape
+    labels = (torch.rand(D, H, W, generator=torch.Generator().manual_seed(3)) < 0.4).to(torch.int8)
+    labels[:3] = -1
+    item = TomogramData(sample="S", tomo_name="t.hdf", split_id=0, data=vol[None].clone(), label=labels, aux_data={"data": vol.numpy()})
+    batch = collate_fn([item])
+    assert tuple(batch.tomo_batch.shape) == (1, D, 1, H, W)
+    res = model.test_step(batch)
+    want = torch.from_numpy(g["probs"])[0]
+    assert float((torch.from_numpy(res.preds[0]) - want).abs().max()) <= 1.5e-2
+    m = labels > -1
+    ph = (want >= 0.5).float()
+    dice_ref = dice_from_sums(float((labels.float() * ph)[m].sum()), float(labels.float()[m].sum()), float(ph[m].sum()))
+    loss_ref = float(tp.masked_dice_loss(want, labels.float()))
+    assert abs(res.metrics["dice_metric"] - dice_ref) <= 5e-3 and abs(res.losses["dice_loss"] - loss_ref) <= 2e-3
+    assert abs(res.losses["total"] - res.losses["dice_loss"]) < 1e-12
+    assert abs(model.validation_step(batch) - res.losses["dice_loss"]) < 1e-7
