@@ -91,8 +91,8 @@ def run_trainer(cfg) -> None:
 
     callbacks = [instantiate(cb_cfg) for cb_cfg in cfg.callbacks.values()]
     device = select_device((cfg.get("trainer") or {}).get("device"))
-    if cfg.model._target_.rsplit(".", 1)[-1] != "CryoVIT":
-        raise NotImplementedError(f"{cfg.model._target_}: only the CryoVIT head is built (SAM2 / UNet3D / MedSAM are out of scope)")
+    if cfg.model._target_.rsplit(".", 1)[-1] not in ("CryoVIT", "UNet3D"):
+        raise NotImplementedError(f"{cfg.model._target_}: the CryoVIT head and the UNet3D baseline are built (SAM2 / MedSAM segmentation are out of scope)")
     model = instantiate(cfg.model, device=device)
     if cfg.ckpt_path.suffix == ".pt":
         # weights_only: a state_dict needs nothing else, and nothing from the file is ever executed

@@ -175,3 +175,56 @@ def test_unet3d_evaluation_protocol(gpu, gold):
     assert abs(res.metrics["dice_metric"] - dice_ref) <= 5e-3 and abs(res.losses["dice_loss"] - loss_ref) <= 2e-3
     assert abs(res.losses["total"] - res.losses["dice_loss"]) < 1e-12
     assert abs(model.validation_step(batch) - res.losses["dice_loss"]) < 1e-7
+
+
+def test_eval_model_entry_point_unet3d(gpu, tmp_path):
+    """``python -m cryovit_amd.training.eval_model model=unet3d`` from files on disk (weights.pt in the reference's state_dict
+    layout, raw uint8 ``data`` volumes + ``labels/mito``): the metrics CSV and the prediction files against the fp32 CPU oracle
+    (restatement pinned bit-for-bit to the reference's UNet3D classes) on the same weights."""
+    import csv
+
+    from cryovit_amd import io
+    from cryovit_amd.training import eval_model as entry
+    from oracle import dice as od
+    from oracle import unet3d as ou
+
+    ref = ou.UNet3D(ou.REF_WIDTHS)
+    ou.rescaled_init_(ref, seed=23)
+    data_dir, exp_dir = tmp_path / "data", tmp_path / "exp"
+    name = "single_any_unet3d_mito"
+    (exp_dir / name / "Q109" / "split_1").mkdir(parents=True)
+    torch.save(ref.state_dict(), exp_dir / name / "Q109" / "split_1" / "weights.pt")
+    (data_dir / "csv").mkdir(parents=True)
+    rng = np.random.default_rng(41)
+    rows, truth = [], {}
+    for i, (D, split) in enumerate(((12, 1), (16, 0))):
+        vol = rng.integers(0, 256, size=(D, 24, 20), dtype=np.uint8)
+        lab = rng.integers(-1, 2, size=(D, 24, 20)).astype(np.int8)
+        p = data_dir / "tomograms" / "Q109" / f"u{i}.hdf"
+        p.parent.mkdir(parents=True, exist_ok=True)
+        with io.FileWriter(p) as f:
+            f.create_dataset("data", vol, compression="gzip")
+            f.create_dataset("labels/mito", lab, compression="gzip")
+        rows.append({"sample": "Q109", "tomo_name": f"u{i}.hdf", "split_id": split})
+        truth[f"u{i}.hdf"] = (vol, lab)
+    with open(data_dir / "csv" / "splits.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["sample", "tomo_name", "split_id"])
+        w.writeheader()
+        w.writerows(rows)
+    entry.main(["model=unet3d", "datamodule=single", "datamodule.sample=Q109", "datamodule.split_id=1", "label_key=mito",
+                f"paths.model_dir={tmp_path}", f"paths.data_dir={data_dir}", f"paths.exp_dir={exp_dir}", f"paths.results_dir={tmp_path / 'results'}"])
+    got = list(csv.DictReader(open(tmp_path / "results" / "results" / name / "Q109_1.csv")))
+    assert [r["tomo_name"] for r in got] == ["u0.hdf"]
+    vol, lab = truth["u0.hdf"]
+    with torch.no_grad():
+        probs = ref.forward_tomo_batch(torch.from_numpy(vol.astype(np.float32) / 255.0)[None, :, None])[0]  # uint8 -> /255 (tomo_dataset.py:118)
+    labt = torch.from_numpy(lab).float()
+    pred = tmp_path / "results" / "predictions" / name / "Q109" / "u0.hdf"
+    pp = io.read_dataset(pred, "mito_preds")
+    assert pp.dtype == np.float32 and pp.shape == lab.shape
+    err = np.abs(pp - probs.numpy())
+    print(f"unet3d eval_model: prob err max {err.max():.2e} mean {err.mean():.2e}")
+    assert err.max() <= 3e-2 and err.mean() <= 2e-3
+    # Dice of thresholded predictions: exact given the GPU's own probabilities, and close to the oracle's where no voxel sits on the threshold
+    assert abs(float(got[0]["dice_metric"]) - od.dice_metric(torch.from_numpy(pp), labt)) <= 1e-6
+    assert abs(float(got[0]["dice_metric"]) - od.dice_metric(probs, labt)) <= 2e-2
