@@ -78,3 +78,9 @@ class UNet3D(EvalProtocol, nn.Module):
         if x.shape[2] != 1:
             raise ValueError(f"UNet3D expects the raw single-channel volume ('{self.input_key}'), got {x.shape[2]} channels")
         return torch.stack([self.engine().forward(xb[:, 0]) for xb in x])
+
+    @torch.inference_mode()
+    def predict_mask(self, batch, threshold: float = 0.5) -> list[Tensor]:
+        """``predict_step`` + ``PredictionWriter``'s threshold (base_model.py:243-273, callbacks.py:100-102): per tomogram the uint8
+        segmentation ``forward(batch) >= threshold`` [D, H, W] (device tensors)."""
+        return [(self.engine().forward(xb[:, 0]) >= threshold).to(torch.uint8) for xb in batch.tomo_batch]

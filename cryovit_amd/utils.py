@@ -343,8 +343,8 @@ def load_model(model_path, load_model: bool = True, device="cuda:0"):
     if load_model:
         cfg = Cfg(saved["model_cfg"]) if not isinstance(saved["model_cfg"], Cfg) else saved["model_cfg"]
         target = str(cfg.get("_target_", ""))
-        if not target.endswith(".CryoVIT"):
-            raise NotImplementedError(f"model target {target!r}: only the CryoVIT head runs on this build (SURVEY s.8)")
+        if not target.endswith((".CryoVIT", ".UNet3D")):
+            raise NotImplementedError(f"model target {target!r}: the CryoVIT head and the UNet3D baseline run on this build (SURVEY s.8)")
         model = instantiate(cfg, device=device)
         model.load_state_dict(saved["weights"])
     return model, ModelType(saved["model_type"]), saved["name"], saved["label_key"]

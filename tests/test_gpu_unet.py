@@ -228,3 +228,33 @@ def test_eval_model_entry_point_unet3d(gpu, tmp_path):
     # Dice of thresholded predictions: exact given the GPU's own probabilities, and close to the oracle's where no voxel sits on the threshold
     assert abs(float(got[0]["dice_metric"]) - od.dice_metric(torch.from_numpy(pp), labt)) <= 1e-6
     assert abs(float(got[0]["dice_metric"]) - od.dice_metric(probs, labt)) <= 2e-2
+
+
+def test_run_inference_unet3d(gpu, tmp_path):
+    """``run_inference`` (``cryovit infer``) with a UNet3D ``.model`` container on a raw tomogram file: uint8 segmentation against the
+    oracle's probabilities (disagreement only where the oracle sits within 3e-2 of the threshold)."""
+    from cryovit_amd import io
+    from cryovit_amd.run.infer_model import run_inference
+    from cryovit_amd.types import ModelType
+    from cryovit_amd.utils import load_data, save_model_from_weights
+    from oracle import unet3d as ou
+
+    ref = ou.UNet3D(ou.REF_WIDTHS)
+    ou.rescaled_init_(ref, seed=29)
+    torch.save(ref.state_dict(), tmp_path / "weights.pt")
+    save_model_from_weights("unet_demo", "mito", ModelType.UNET3D, tmp_path / "weights.pt", tmp_path / "unet.model")
+    vol = np.random.default_rng(12).integers(0, 256, size=(10, 20, 24), dtype=np.uint8)
+    (tmp_path / "in").mkdir()
+    with io.FileWriter(tmp_path / "in" / "raw0.hdf") as f:
+        f.create_dataset("data", vol, compression="gzip")
+    thr = 0.6
+    paths = run_inference([tmp_path / "in" / "raw0.hdf"], tmp_path / "unet.model", tmp_path / "out", threshold=thr)
+    assert paths == [tmp_path / "out" / "raw0.hdf"] and sorted(io.list_keys(paths[0])) == ["data", "mito_preds"]
+    seg = io.read_dataset(paths[0], "mito_preds")
+    assert seg.dtype == np.uint8 and seg.shape == vol.shape
+    x = torch.from_numpy(np.ascontiguousarray(load_data(tmp_path / "in" / "raw0.hdf", key="data")[0].squeeze(0), dtype=np.float32))  # the loader's normalisation
+    with torch.no_grad():
+        probs = ref.forward_tomo_batch(x[None, :, None])[0].numpy()
+    want = (probs >= thr).astype(np.uint8)
+    bad = seg != want
+    assert bad.mean() <= 0.02 and np.all(np.abs(probs[bad] - thr) < 3e-2), (bad.mean(), np.abs(probs[bad] - thr).max() if bad.any() else 0)
