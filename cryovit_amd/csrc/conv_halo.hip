@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void k_conv3_march(const uint16_t* __restrict_
     const char* zp = (const char*)zero_page;
     __syncthreads();
 
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // XCD-aware order: workgroups b and b + 8 share an XCD (and its L2), so each XCD takes a contiguous run of columns -- neighbouring
+    // columns read each other's halo rows / voxels from the same L2 instead of eight different ones
+    const int vb = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    for (int item = vb; item < nitems; item += gridDim.x) {
         const int r = item % dil, col = item / dil;
         const int tx = col % tiles_x, ty = col / tiles_x;
         const int x0 = tx * CH_TX - 1, y0 = ty * CH_TY - 1;
