@@ -29,7 +29,10 @@ __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ 
     for (int i = threadIdx.x; i < 27 * 4; i += 256) sw2[i] = pack2h(w[2 * i], w[2 * i + 1]);
     float inter = 0.f, ysum = 0.f, psum = 0.f;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // XCD-aware order (workgroups b and b + 8 share an L2): each XCD walks a contiguous run of tiles per pass, so the rows a tile's
+    // neighbours staged are found in the same L2
+    const long vb = (gridDim.x & 7) == 0 ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    for (long tile = vb; tile < ntiles; tile += gridDim.x) {
         const int tx = (int)(tile % tiles_x);
         const long t2 = tile / tiles_x;
         const int ty = (int)(t2 % tiles_y), z = (int)(t2 / tiles_y);
