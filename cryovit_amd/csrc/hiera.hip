@@ -79,9 +79,23 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
     __shared__ __attribute__((aligned(16))) uint16_t Vs[64 * LDR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int head = blockIdx.y % heads, win = blockIdx.y / heads;
+    // XCD-aware block order: linear ids b and b + 8 share an XCD (and its L2).  The query blocks of one (slice, window, head) read the
+    // same K / V rows: re-numbering the grid so that an XCD takes a contiguous run of linear ids puts them behind one L2.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned long nb = (unsigned long)gridDim.x * gridDim.y * gridDim.z;
+        if ((nb & 7) == 0) {
+            const unsigned long lin = bx + (unsigned long)gridDim.x * (by + (unsigned long)gridDim.y * bz);
+            const unsigned long vb = (lin & 7) * (nb >> 3) + (lin >> 3);
+            bx = (unsigned)(vb % gridDim.x);
+            const unsigned long t = vb / gridDim.x;
+            by = (unsigned)(t % gridDim.y);
+            bz = (unsigned)(t / gridDim.y);
+        }
+    }
+    const int head = by % heads, win = by / heads;
     const int nwx = G / ws, wy = win / nwx, wx = win % nwx;
-    const long d = blockIdx.z;
+    const long d = bz;
     const int nq = wsq * wsq, nk = ws * ws;
     const int nthreads = blockDim.x;
 
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
     }
 
     // this lane's query (B operand: column q = li, k = 16s + 4g .. +3)
-    const int ql = blockIdx.x * 64 + wave * 16 + li;
+    const int ql = bx * 64 + wave * 16 + li;
     const bool q_ok = ql < nq;
     const int qc = q_ok ? ql : 0;
     const long qrow = d * Gq * Gq + (long)(wy * wsq + qc / wsq) * Gq + wx * wsq + qc % wsq;
