@@ -14,7 +14,7 @@ import os
 LIB_PATH = Path(__file__).resolve().parent / ("libcryovit_hip_ablation.so" if os.environ.get("CVX_ABLATION_LIB") == "1"
                                                 else "libcryovit_hip.so")
 
-EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT, EPI_F32 = range(8)
+EPI_BF16, EPI_BF16_GELU, EPI_SWIGLU, EPI_RESID, EPI_PATCH, EPI_VT, EPI_CONVT, EPI_F32, EPI_RESID_HL = range(9)
 DTYPE_BF16, DTYPE_F16 = 0, 1  # CVX_DTYPE_*
 DICE_BLOCKS = 4096  # CVX_DICE_BLOCKS
 GN_BLOCKS = 1024  # CVX_GN_BLOCKS
@@ -36,6 +36,8 @@ class GemmDesc(C.Structure):
         ("npatch", c_int), ("ntp", c_int), ("tok0", c_int),
         ("heads", c_int), ("kp", c_int),
         ("H", c_int), ("W", c_int), ("cout", c_int), ("act", c_int), ("dtype", c_int), ("convt_up_z", c_int),
+        ("ln_rowstat", c_void_p),
+        ("out2", c_void_p), ("stat_part", c_void_p), ("stat_rows", c_long),
     ]
 
 
@@ -54,12 +56,12 @@ class VitLayer(C.Structure):
 
 class VitDesc(C.Structure):
     _fields_ = [("dim", c_int), ("depth", c_int), ("heads", c_int), ("n_reg", c_int), ("ffn_swiglu", c_int), ("hid_pad", c_int),
-                ("ln_eps", c_float), ("pe_b", c_void_p), ("reg", c_void_p), ("norm_w", c_void_p), ("norm_b", c_void_p),
+                ("ln_eps", c_float), ("ln_fold", c_int), ("pe_b", c_void_p), ("reg", c_void_p), ("norm_w", c_void_p), ("norm_b", c_void_p),
                 ("layers", C.POINTER(VitLayer))]
 
 
 class VitWs(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("x", "xn", "qk", "vt", "ao", "hid")]
+    _fields_ = [(n, c_void_p) for n in ("x", "xn", "qk", "vt", "ao", "hid", "xh", "xl", "stat_part", "rowstat")]
 
 
 class HeadBlock(C.Structure):
@@ -109,6 +111,10 @@ SIGNATURES = {
     "cvx_init_tokens": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cvx_final_norm_features": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),
+    "cvx_final_norm_features_hl": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,
+                                           c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),
+    "cvx_split_stream": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p]),
+    "cvx_rowstat_finalize": (c_int, [c_void_p, c_int, c_long, c_void_p, c_long, c_int, c_float, c_void_p]),
     "cvx_im2col_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "cvx_features_to_channels_last": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "cvx_groupnorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),

@@ -6,7 +6,7 @@ test suite -- hipcc cross-compiles without a GPU):
 
   * no scratch: a register spill is a scratch store / load, i.e. an uncounted entry in the in-order vmcnt queue;
   * the epilogue of an interior-tile ("FULL") kernel issues exactly ``epi_stores_per_wave`` global stores (8 SwiGLU, 16 bf16 /
-    fp16, 32 fp32) -- hipcc splits and merges the stores it generates itself, the kernel's come from inline asm;
+    fp16, 32 fp32, 33 bf16 hi / lo pair + row statistics) -- hipcc splits and merges the stores it generates itself, the kernel's come from inline asm;
   * every LDS-DMA is the inline-asm saddr form (``global_load_lds_dwordx4 vOFF, s[BASE]``): the builtin form would let hipcc
     cache what it believes M0 holds across the asm statements that rewrite it.
 """
@@ -21,7 +21,7 @@ from pathlib import Path
 
 from cryovit_amd.build import ARCH, CSRC, FILE_FLAGS, FLAGS, INCLUDE, hipcc_path
 
-EXPECTED_STORES = {"EpiSwiGLU": 8, "EpiBF16": 16, "EpiResidT": 32, "EpiVT": 16}
+EXPECTED_STORES = {"EpiSwiGLU": 8, "EpiBF16": 16, "EpiResidT": 32, "EpiResidHL": 33, "EpiVT": 16}
 
 
 def compile_asm(src: Path) -> str:

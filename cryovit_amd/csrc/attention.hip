@@ -461,7 +461,11 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     if (slices <= 0) return 0;
     if (ntp % 8 || kp % 64 || kp < ntok || ntp < ntok || ldqk % 8 || ldo % 4)
         return cvx_fail("attention: need ntp%8==0, kp%64==0, kp>=ntok, ntp>=ntok, ldqk%8==0");
-    const int variant = g_attn_variant;  // one read per call: a concurrent cvx_set_option cannot give a mixed launch
+    int variant = g_attn_variant;  // one read per call: a concurrent cvx_set_option cannot give a mixed launch
+    // Variant 6's single-wave query blocks derive the departed waves' DMA offsets by XOR-ing 64 into wave 0's own, which is the other
+    // waves' row term only while a K row's byte pitch is a multiple of 128 (ldqk % 64 == 0: every DINOv2 width).  Other leading
+    // dimensions take the general kernel with the same arithmetic plan (variant 3).
+    if (variant == 6 && ldqk % 64 != 0) variant = 3;
     const int rows_per_block = variant == 4 ? 192 : variant == 5 ? 256 : 128;
     const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;

@@ -57,33 +57,53 @@ __device__ __forceinline__ void load_vec(float* dst, const float* src) {
     }
 }
 
+// LayerNorm folded into a consuming GEMM (LN = true; DESIGN.md s.4 "LayerNorm fold"): the A operand is bf16(x) itself (the `hi`
+// half of the residual stream), the LayerNorm gain is folded into the weights at packing (W' = bf16(W * gamma_ln)), and the
+// normalisation is applied to the ACCUMULATOR:  y[m][n] = rstd[m] * acc - mu[m] * rstd[m] * cs[n] + b'[n]  with
+// cs[n] = sum_c W'[n][c] and b'[n] = b[n] + sum_c W[n][c] * beta_ln[c].  `bias` then points at [2][cs_off] floats (b' | cs) and
+// `rowstat` at fp32 [rows][2] = (rstd, -mu * rstd), written by cvx_rowstat_finalize / cvx_split_stream.
+__device__ __forceinline__ float ln_fold(float acc, float2 rs, float cs, float b) { return fmaf(acc, rs.x, fmaf(rs.y, cs, b)); }
+
 // out[m][n] = bf16 | fp16 (act(acc + bias[n]));  ACT: 0 none, 1 GELU(erf);  HALF: fp16 operands and output (the head)
-template <int ACT, bool HALF = false>
+template <int ACT, bool HALF = false, bool LN = false>
 struct EpiBF16 {
     static constexpr bool F16 = HALF;
+    static constexpr bool LNFOLD = LN;
     uint16_t* out; long ldc; const float* bias; long m_valid, n_valid;
+    const float* rowstat = nullptr; long cs_off = 0;  // LN only
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
-    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const { load_vec<NV>(c.bias, bias + n0); }
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const {
+        load_vec<NV>(c.bias, bias + n0);
+        if constexpr (LN) load_vec<NV>(c.gamma, bias + cs_off + n0);  // (the gamma slot carries the column sums)
+    }
     template <int NV>
     __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
         if (m >= m_valid) return;
+        float2 rs{0.f, 0.f};
+        if constexpr (LN) rs = *(const float2*)(rowstat + 2 * m);
         float v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const float t = acc[i] + c.bias[i];
+            const float t = LN ? ln_fold(acc[i], rs, c.gamma[i], c.bias[i]) : acc[i] + c.bias[i];
             v[i] = ACT == 1 ? gelu_erf(t) : t;
         }
         store_bf16_chunked<NV, HALF>(out + m * ldc + n0, v, n0, n_valid);
     }
     // the same epilogue for rows [m_off, ...) of the problem when A is passed advanced by m_off rows (tail launches)
-    EpiBF16 shifted(long m_off) const { return EpiBF16{out + m_off * ldc, ldc, bias, m_valid - m_off, n_valid}; }
+    EpiBF16 shifted(long m_off) const {
+        EpiBF16 e = *this;
+        e.out = out + m_off * ldc; e.m_valid = m_valid - m_off;
+        if (rowstat) e.rowstat = rowstat + 2 * m_off;
+        return e;
+    }
     // LDS-staged row-major store (gemm256.h): 16 accumulators -> OUT16 packed bf16 outputs of column n0 >> OUT_SHIFT
     static constexpr int OUT16 = 16, OUT_SHIFT = 0;
-    __device__ __forceinline__ void produce(const Ctx<16>& c, const float* acc, uint32_t (&w)[8]) const {
+    __device__ __forceinline__ void produce(const Ctx<16>& c, const float* acc, uint32_t (&w)[8], float2 rs = float2{0.f, 0.f}) const {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float a = acc[2 * i] + c.bias[2 * i], b = acc[2 * i + 1] + c.bias[2 * i + 1];
+            const float a = LN ? ln_fold(acc[2 * i], rs, c.gamma[2 * i], c.bias[2 * i]) : acc[2 * i] + c.bias[2 * i];
+            const float b = LN ? ln_fold(acc[2 * i + 1], rs, c.gamma[2 * i + 1], c.bias[2 * i + 1]) : acc[2 * i + 1] + c.bias[2 * i + 1];
             w[i] = pack2x<HALF>(ACT == 1 ? gelu_erf(a) : a, ACT == 1 ? gelu_erf(b) : b);
         }
     }
@@ -91,30 +111,53 @@ struct EpiBF16 {
 
 // SwiGLU gate: packed W12 rows are interleaved in blocks of 8 (a[8j..8j+7], b[8j..8j+7]) so a lane's 16
 // contiguous accumulators are 8 a's and the 8 matching b's:  out[m][n0/2 + i] = silu(a_i) * b_i
-struct EpiSwiGLU {
+template <bool LN = false>
+struct EpiSwiGLUT {
+    static constexpr bool LNFOLD = LN;
     uint16_t* out; long ldc; const float* bias; long m_valid, n_valid;
+    const float* rowstat = nullptr; long cs_off = 0;  // LN only (see EpiBF16)
     template <int NV> using Ctx = VecCtx<NV>;
     template <int NV>
-    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const { load_vec<NV>(c.bias, bias + n0); }
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const {
+        load_vec<NV>(c.bias, bias + n0);
+        if constexpr (LN) load_vec<NV>(c.gamma, bias + cs_off + n0);
+    }
     template <int NV>
     __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
         static_assert(NV == 16, "SwiGLU epilogue needs 16 contiguous features per lane");
         if (m >= m_valid || n0 >= n_valid) return;
+        float2 rs{0.f, 0.f};
+        if constexpr (LN) rs = *(const float2*)(rowstat + 2 * m);
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = silu(acc[i] + c.bias[i]) * (acc[8 + i] + c.bias[8 + i]);
+        for (int i = 0; i < 8; ++i) {
+            const float a = LN ? ln_fold(acc[i], rs, c.gamma[i], c.bias[i]) : acc[i] + c.bias[i];
+            const float b = LN ? ln_fold(acc[8 + i], rs, c.gamma[8 + i], c.bias[8 + i]) : acc[8 + i] + c.bias[8 + i];
+            v[i] = silu(a) * b;
+        }
         store_bf16_chunked<8>(out + m * ldc + (n0 >> 1), v, 0, 1);
     }
-    EpiSwiGLU shifted(long m_off) const { return EpiSwiGLU{out + m_off * ldc, ldc, bias, m_valid - m_off, n_valid}; }
+    EpiSwiGLUT shifted(long m_off) const {
+        EpiSwiGLUT e = *this;
+        e.out = out + m_off * ldc; e.m_valid = m_valid - m_off;
+        if (rowstat) e.rowstat = rowstat + 2 * m_off;
+        return e;
+    }
     static constexpr int OUT16 = 8, OUT_SHIFT = 1;  // 8 gated outputs per 16 accumulators, output column = n0 / 2
     // Written on register-adjacent PAIRS (accumulator elements 2i, 2i+1 of one fragment): packed adds / multiplies, two exp2,
     // two rcp and one packed convert per two outputs.  Left to the SLP vectoriser the same arithmetic came out with the pairs
     // crossed (a_i with b_i): 10 instructions per output, a quarter of them v_mov / v_or shuffles.
-    __device__ __forceinline__ void produce(const Ctx<16>& c, const float* acc, uint32_t (&w)[4]) const {
+    __device__ __forceinline__ void produce(const Ctx<16>& c, const float* acc, uint32_t (&w)[4], float2 rs = float2{0.f, 0.f}) const {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const f32x2 a = f32x2{acc[2 * i], acc[2 * i + 1]} + f32x2{c.bias[2 * i], c.bias[2 * i + 1]};
-            const f32x2 b = f32x2{acc[8 + 2 * i], acc[9 + 2 * i]} + f32x2{c.bias[8 + 2 * i], c.bias[9 + 2 * i]};
+            f32x2 a, b;
+            if constexpr (LN) {
+                a = f32x2{acc[2 * i], acc[2 * i + 1]} * rs.x + (f32x2{c.gamma[2 * i], c.gamma[2 * i + 1]} * rs.y + f32x2{c.bias[2 * i], c.bias[2 * i + 1]});
+                b = f32x2{acc[8 + 2 * i], acc[9 + 2 * i]} * rs.x + (f32x2{c.gamma[8 + 2 * i], c.gamma[9 + 2 * i]} * rs.y + f32x2{c.bias[8 + 2 * i], c.bias[9 + 2 * i]});
+            } else {
+                a = f32x2{acc[2 * i], acc[2 * i + 1]} + f32x2{c.bias[2 * i], c.bias[2 * i + 1]};
+                b = f32x2{acc[8 + 2 * i], acc[9 + 2 * i]} + f32x2{c.bias[8 + 2 * i], c.bias[9 + 2 * i]};
+            }
             const f32x2 t = a * -1.4426950408889634f;
             const f32x2 u = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
             const f32x2 r = f32x2{__builtin_amdgcn_rcpf(u[0]), __builtin_amdgcn_rcpf(u[1])};
@@ -123,6 +166,7 @@ struct EpiSwiGLU {
         }
     }
 };
+using EpiSwiGLU = EpiSwiGLUT<false>;
 
 // residual stream update in fp32:  x[m][n] += gamma[n] * (acc + bias[n])
 // x[m][n] (+)= gamma[n] * (acc + bias[n]) on the fp32 stream.  ACC = true: read-modify-write (LayerScale + residual);
@@ -188,6 +232,61 @@ struct EpiResidT {
 using EpiResid = EpiResidT<true>;
 using EpiF32 = EpiResidT<false>;
 
+// The residual stream as a PAIR of bf16 arrays: hi = bf16(x) is at the same time the A operand of the next
+// GEMM (whose epilogue applies the folded LayerNorm), lo = bf16(x - hi) keeps 16 significant bits of the running sum
+// (x is read back as hi + lo, exact in fp32).  Same bytes as one fp32 array, but the separate LayerNorm pass (read 4 B, write
+// 2 B per element, 80 times per slice batch) is gone.   x += gamma * (acc + bias);  hi, lo = split(x);  and per 64-column slot
+// the row sums  part[slot][m] = (sum x, sum x^2)  of the NEW x (fp32, before the split) for cvx_rowstat_finalize.
+struct EpiResidHL {
+    static constexpr bool HAS_HL = true;
+    uint16_t* xh; uint16_t* xl; long ldx; const float* bias; const float* gamma; float* part; long part_rows; long m_valid, n_valid;
+    template <int NV> using Ctx = VecCtx<NV>;
+    template <int NV>
+    __device__ __forceinline__ void prep(Ctx<NV>& c, long n0) const {
+        load_vec<NV>(c.bias, bias + n0);
+        load_vec<NV>(c.gamma, gamma + n0);
+    }
+    EpiResidHL shifted(long m_off) const {
+        EpiResidHL r = *this;
+        r.xh = xh + m_off * ldx; r.xl = xl + m_off * ldx; r.part = part + m_off * 2; r.m_valid = m_valid - m_off;
+        return r;
+    }
+    // accumulator-layout form (the 128 / 64-wide tiles: tails and small problems): 16 contiguous columns n0.. of row m per lane,
+    // the four lane groups of a wave cover one 64-column slot.  Every lane runs the shuffles (no early exit).
+    template <int NV>
+    __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
+        static_assert(NV == 16, "hi/lo residual epilogue: 16 contiguous columns per lane (64-column slots)");
+        const bool ok = m < m_valid;
+        const long mm = ok ? m : 0;
+        const uint16_t* ph = xh + mm * ldx + n0;
+        const uint16_t* pl = xl + mm * ldx + n0;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint4 vh = *(const uint4*)(ph + 8 * h), vl = *(const uint4*)(pl + 8 * h);
+            const uint32_t wh[4] = {vh.x, vh.y, vh.z, vh.w}, wl[4] = {vl.x, vl.y, vl.z, vl.w};
+            uint32_t nh[4], nl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 8 * h + 2 * k;
+                const float x0 = (bflo(wh[k]) + bflo(wl[k])) + c.gamma[i] * (acc[i] + c.bias[i]);
+                const float x1 = (bfhi(wh[k]) + bfhi(wl[k])) + c.gamma[i + 1] * (acc[i + 1] + c.bias[i + 1]);
+                nh[k] = pack2bf(x0, x1);
+                nl[k] = pack2bf(x0 - bflo(nh[k]), x1 - bfhi(nh[k]));
+                s += x0 + x1;
+                q = fmaf(x0, x0, fmaf(x1, x1, q));
+            }
+            if (ok) {
+                *(uint4*)(xh + m * ldx + n0 + 8 * h) = uint4{nh[0], nh[1], nh[2], nh[3]};
+                *(uint4*)(xl + m * ldx + n0 + 8 * h) = uint4{nl[0], nl[1], nl[2], nl[3]};
+            }
+        }
+        s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+        s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+        if (ok && (threadIdx.x & 48) == 0) *(float2*)(part + ((n0 >> 6) * part_rows + m) * 2) = float2{s, q};
+    }
+};
+
 // patch embedding: GEMM row m = slice*npatch + p  ->  token row slice*ntp + tok0 + p of the fp32 stream,
 // value = acc + bias[n] + pos[(1+p)][n]
 struct EpiPatch {
@@ -218,9 +317,12 @@ struct EpiPatch {
 
 // V written TRANSPOSED for the attention kernel (MREG orientation: a lane owns NV consecutive tokens of one
 // feature n = head*64 + d):   vt[slice][head][d][t] = acc + bias[n],   token row m = slice*ntp + t
-struct EpiVT {
+template <bool LN = false>
+struct EpiVTT {
+    static constexpr bool LNFOLD = LN;
     uint16_t* vt; const float* bias; int heads, ntp, kp; long m_valid, n_valid; long m_off = 0;  // m_off: row of the problem that A row 0 is
-    EpiVT shifted(long off) const { EpiVT e = *this; e.m_off = m_off + off; e.m_valid = m_valid - off; return e; }
+    const float* rowstat = nullptr; long cs_off = 0;  // LN only (see EpiBF16); rowstat is indexed by the PROBLEM row (m + m_off)
+    EpiVTT shifted(long off) const { EpiVTT e = *this; e.m_off = m_off + off; e.m_valid = m_valid - off; return e; }
     template <int NV> struct Ctx {};
     template <int NV>
     __device__ __forceinline__ void prep(Ctx<NV>&, long) const {}
@@ -244,6 +346,7 @@ struct EpiVT {
         static_assert(NV % 8 == 0, "V^T epilogue stores 8 tokens (16 B) at a time");
         if (n >= n_valid) return;
         const float b = bias[n];
+        const float cs = LN ? bias[cs_off + n] : 0.f;
         const long head = n >> 6, d = n & 63;
 #pragma unroll
         for (int h = 0; h < NV / 8; ++h) {
@@ -252,11 +355,15 @@ struct EpiVT {
             const long s = m8 / ntp, t = m8 - s * ntp;  // ntp % 8 == 0: a group of 8 never straddles slices
             float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = acc[h * 8 + i] + b;
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (LN) v[i] = ln_fold(acc[h * 8 + i], *(const float2*)(rowstat + 2 * (m8 + i)), cs, b);
+                else v[i] = acc[h * 8 + i] + b;
+            }
             store_bf16_chunked<8>(vt + ((s * heads + head) * 64 + d) * (long)kp + t, v, 0, 1);
         }
     }
 };
+using EpiVT = EpiVTT<false>;
 
 // ConvTranspose3d kernel=stride=(1,2,2) as a GEMM with N = 4*Cout (n = (i*2+j)*Cout + o), pixel-shuffle
 // scatter into the channels-last output [D][2H][2W][Cout], GELU fused.  bias is pre-expanded to N entries.
@@ -465,7 +572,7 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
         return cvx_check_launch();
     }
     const int variant = g_gemm256_variant;
-    if constexpr ((!MREG && (epi_has_preload<Epi>::value || epi_has_produce<Epi>::value)) || (MREG && epi_is_mreg<Epi>::value)) {
+    if constexpr ((!MREG && (epi_has_preload<Epi>::value || epi_has_produce<Epi>::value || epi_has_hl<Epi>::value)) || (MREG && epi_is_mreg<Epi>::value)) {
         if (variant == 9 || variant == 29) {
             // one workgroup per CU (128 KiB of LDS each), a multiple of 8 so every XCD gets the same number
             static int n_cu = 0;
@@ -489,8 +596,8 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
             }
             CVX_HIP(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, G256P_LDS_BYTES));
             hipLaunchKernelGGL(kp, dim3(grid), dim3(G256_THREADS), G256P_LDS_BYTES, st, A, lda, Wt, ldw, (int)(Kpad / BK), tiles_n, tiles_m,
-                               (epi_has_preload<Epi>::value && g_resid_reverse ? -1 : 1) * (int)g_tile_group_l_host,
-                               ntiles > grid ? (epi_has_preload<Epi>::value ? (int)g_resid_stagger : (int)g_gemm_stagger) : 0, epi);
+                               ((epi_has_preload<Epi>::value || epi_has_hl<Epi>::value) && g_resid_reverse ? -1 : 1) * (int)g_tile_group_l_host,
+                               ntiles > grid ? ((epi_has_preload<Epi>::value || epi_has_hl<Epi>::value) ? (int)g_resid_stagger : (int)g_gemm_stagger) : 0, epi);
             return cvx_check_launch();
         }
     }
@@ -557,7 +664,7 @@ static int launch_256_split(const uint16_t* A, long lda, const uint16_t* Wt, lon
     if constexpr (epi_can_shift<Epi>::value) {
         // (the 128-tile kernel's fp32 read-modify-write epilogue is not LDS-staged: with a short K loop the tail would cost
         //  more than the idle round it removes -- measured on the proj GEMM)
-        const long m_main = tail_split_rows(M, Npad, !epi_has_preload<Epi>::value || Kpad >= 2048 || g_tail_split == 2);
+        const long m_main = tail_split_rows(M, Npad, !(epi_has_preload<Epi>::value || epi_has_hl<Epi>::value) || Kpad >= 2048 || g_tail_split == 2);
         if (m_main < M) {
             int rc = launch_256<Epi, false>(A, lda, Wt, ldw, m_main, Npad, Kpad, epi, st);
             if (rc) return rc;
@@ -577,9 +684,11 @@ static int dispatch_nreg(const uint16_t* A, long lda, const uint16_t* Wt, long l
     if (use_gemm256(M, Npad, Kpad)) return launch_256_split(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 128 == 0) return launch_nreg<TileCfg<128, 128, 2>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
     if (Npad % 64 == 0) return launch_nreg<TileCfg<64, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
-    if (Npad % 32 == 0) return launch_nreg<TileCfg<32, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
-    if (Npad % 16 == 0) return launch_nreg<TileCfg<16, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
-    return cvx_fail("gemm: N must be padded to a multiple of 16");
+    if constexpr (!epi_has_hl<Epi>::value) {  // (the hi/lo residual epilogue works on 64-column slots)
+        if (Npad % 32 == 0) return launch_nreg<TileCfg<32, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+        if (Npad % 16 == 0) return launch_nreg<TileCfg<16, 256, 1>>(A, lda, Wt, ldw, M, Npad, Kpad, epi, st);
+    }
+    return cvx_fail("gemm: N must be padded to a multiple of 16 (64 for the hi/lo residual epilogue)");
 }
 
 template <class Cfg, class Epi>
@@ -729,6 +838,37 @@ extern "C" int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t st) {
     return gemm_dispatch(d, st);
 }
 
+// V^T GEMM (MREG orientation): whole rounds on the persistent 256 tile, the rest (or a small problem) on 64 x 128 / 128 x 128 tiles
+template <class E>
+static int dispatch_vt(const cvx_gemm_desc* d, const uint16_t* A, const uint16_t* W, const E& e, hipStream_t st) {
+    using Cfg = TileCfg<128, 128, 2>;
+    auto tail128 = [&](const uint16_t* a, long m, const E& ev) {
+        const int tiles_n = (int)(d->n_pad / Cfg::BL), tiles_m = (int)((m + Cfg::BR - 1) / Cfg::BR);
+        auto k = k_gemm_mreg<Cfg, E>;
+        CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, a, d->lda, W, d->ldw,
+                           (int)(d->k_pad / BK), tiles_n, tiles_m, ev);
+        return cvx_check_launch();
+    };
+    if (use_gemm256(d->m, d->n_pad, d->k_pad)) {
+        const long m_main = tail_split_rows(d->m, d->n_pad);
+        int rc = launch_256<E, true>(A, d->lda, W, d->ldw, m_main, d->n_pad, d->k_pad, e, st);
+        if (rc || m_main == d->m) return rc;
+        if (g_tail_tile && (d->m - m_main) / 256 * (d->n_pad / 256) * 8 <= 256) {
+            using CfgS = TileCfg<64, 128, 1>;
+            const long m = d->m - m_main;
+            const int tiles_n = (int)(d->n_pad / CfgS::BL), tiles_m = (int)((m + CfgS::BR - 1) / CfgS::BR);
+            auto k = k_gemm_mreg<CfgS, E>;
+            CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CfgS::LDS_BYTES));
+            hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), CfgS::LDS_BYTES, st, A + m_main * d->lda, d->lda, W, d->ldw,
+                               (int)(d->k_pad / BK), tiles_n, tiles_m, e.shifted(m_main));
+            return cvx_check_launch();
+        }
+        return tail128(A + m_main * d->lda, d->m - m_main, e.shifted(m_main));
+    }
+    return tail128(A, d->m, e);
+}
+
 static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
     const uint16_t* A = (const uint16_t*)d->a;
     const uint16_t* W = (const uint16_t*)d->w;
@@ -739,6 +879,10 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         return cvx_fail("gemm: fp16 operands are built for the plain / GELU / ConvT epilogues (the segmentation head)");
     switch (d->epilogue) {
         case CVX_EPI_BF16: {
+            if (d->ln_rowstat) {
+                EpiBF16<0, false, true> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n, d->ln_rowstat, d->n_pad};
+                return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            }
             if (d->dtype == CVX_DTYPE_F16) {
                 EpiBF16<0, true> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
                 return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
@@ -747,6 +891,10 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
         case CVX_EPI_BF16_GELU: {
+            if (d->ln_rowstat) {
+                EpiBF16<1, false, true> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n, d->ln_rowstat, d->n_pad};
+                return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            }
             if (d->dtype == CVX_DTYPE_F16) {
                 EpiBF16<1, true> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
                 return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
@@ -756,6 +904,11 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         }
         case CVX_EPI_SWIGLU: {
             if (d->n_pad % 128) return cvx_fail("gemm: SwiGLU needs N padded to 128");
+            if (d->ln_rowstat) {
+                EpiSwiGLUT<true> e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n, d->ln_rowstat, d->n_pad};
+                if (use_gemm256(d->m, d->n_pad, d->k_pad)) return launch_256_split(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+                return launch_nreg<TileCfg<128, 128, 2>>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+            }
             EpiSwiGLU e{(uint16_t*)d->out, d->ldc, d->bias, d->m, d->n};
             if (use_gemm256(d->m, d->n_pad, d->k_pad)) return launch_256_split(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
             return launch_nreg<TileCfg<128, 128, 2>>(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
@@ -771,6 +924,14 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
 #endif
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
         }
+        case CVX_EPI_RESID_HL: {
+            if (!d->out || !d->out2 || !d->bias || !d->gamma || !d->stat_part)
+                return cvx_fail("gemm: the hi/lo residual epilogue needs out (hi), out2 (lo), bias, gamma and stat_part");
+            if (d->n != d->n_pad || d->n_pad % 64) return cvx_fail("gemm: the hi/lo residual epilogue needs N == n_pad, a multiple of 64");
+            if (d->stat_rows < (d->m + 255) / 256 * 256) return cvx_fail("gemm: stat_rows must cover M rounded up to 256 rows");
+            EpiResidHL e{(uint16_t*)d->out, (uint16_t*)d->out2, d->ldc, d->bias, d->gamma, d->stat_part, d->stat_rows, d->m, d->n};
+            return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);
+        }
         case CVX_EPI_F32: {
             if (!d->out || !d->bias || !d->gamma) return cvx_fail("gemm: the fp32 epilogue needs out, bias and gamma");
             EpiF32 e{(float*)d->out, d->ldc, d->bias, d->gamma, d->m, d->n};
@@ -782,33 +943,12 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         }
         case CVX_EPI_VT: {
             if (d->n_pad % 128 || d->k_pad % BK) return cvx_fail("gemm: V^T epilogue needs N padded to 128, K to 64");
-            EpiVT e{(uint16_t*)d->out, d->bias, d->heads, d->ntp, d->kp, d->m, d->n};
-            using Cfg = TileCfg<128, 128, 2>;
-            auto tail128 = [&](const uint16_t* a, long m, const EpiVT& ev) {
-                const int tiles_n = (int)(d->n_pad / Cfg::BL), tiles_m = (int)((m + Cfg::BR - 1) / Cfg::BR);
-                auto k = k_gemm_mreg<Cfg, EpiVT>;
-                CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-                hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), Cfg::LDS_BYTES, st, a, d->lda, W, d->ldw,
-                                   (int)(d->k_pad / BK), tiles_n, tiles_m, ev);
-                return cvx_check_launch();
-            };
-            if (use_gemm256(d->m, d->n_pad, d->k_pad)) {
-                const long m_main = tail_split_rows(d->m, d->n_pad);
-                int rc = launch_256<EpiVT, true>(A, d->lda, W, d->ldw, m_main, d->n_pad, d->k_pad, e, st);
-                if (rc || m_main == d->m) return rc;
-                if (g_tail_tile && (d->m - m_main) / 256 * (d->n_pad / 256) * 8 <= 256) {
-                    using CfgS = TileCfg<64, 128, 1>;
-                    const long m = d->m - m_main;
-                    const int tiles_n = (int)(d->n_pad / CfgS::BL), tiles_m = (int)((m + CfgS::BR - 1) / CfgS::BR);
-                    auto k = k_gemm_mreg<CfgS, EpiVT>;
-                    CVX_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, CfgS::LDS_BYTES));
-                    hipLaunchKernelGGL(k, dim3(tiles_n * tiles_m), dim3(GEMM_THREADS), CfgS::LDS_BYTES, st, A + m_main * d->lda, d->lda, W, d->ldw,
-                                       (int)(d->k_pad / BK), tiles_n, tiles_m, e.shifted(m_main));
-                    return cvx_check_launch();
-                }
-                return tail128(A + m_main * d->lda, d->m - m_main, e.shifted(m_main));
+            if (d->ln_rowstat) {
+                EpiVTT<true> e{(uint16_t*)d->out, d->bias, d->heads, d->ntp, d->kp, d->m, d->n, 0, d->ln_rowstat, d->n_pad};
+                return dispatch_vt(d, A, W, e, st);
             }
-            return tail128(A, d->m, e);
+            EpiVT e{(uint16_t*)d->out, d->bias, d->heads, d->ntp, d->kp, d->m, d->n};
+            return dispatch_vt(d, A, W, e, st);
         }
         case CVX_EPI_CONVT: {
             if (d->cout % 8) return cvx_fail("gemm: ConvT C_out must be a multiple of 8");

@@ -49,8 +49,14 @@ constexpr int G256P_LDS_BYTES = G256_LDS_BYTES + 8 * 2048;  // ring + two 1-KiB 
 template <class E, class = void> struct epi_is_mreg : std::false_type {};
 template <class E> struct epi_is_mreg<E, std::enable_if_t<E::MREG16>> : std::true_type {};
 
+template <class E, class = void> struct epi_has_hl : std::false_type {};
+template <class E> struct epi_has_hl<E, std::enable_if_t<E::HAS_HL>> : std::true_type {};
+template <class E, class = void> struct epi_is_ln : std::false_type {};
+template <class E> struct epi_is_ln<E, std::enable_if_t<E::LNFOLD>> : std::true_type {};
+
 template <class Epi> constexpr int epi_stores_per_wave() {
     if constexpr (epi_is_mreg<Epi>::value) return 16;                            // 8 fragments x 2 stores of 8 rows
+    else if constexpr (epi_has_hl<Epi>::value) return 33;                        // 8 units x (2 hi + 2 lo) + 1 row-statistics store
 #ifdef CVX_LN_EMIT_PROTO
     else if constexpr (epi_has_preload<Epi>::value) return 49;                   // + 2 x 8 bf16 stores + 1 row-statistics store (prototype)
 #else
@@ -87,7 +93,9 @@ template <class Epi, bool FULL, bool DBG = false>
 __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat, long ldr, const uint16_t* __restrict__ Lmat, long ldl,
                                               int nk, int tiles_r, int tiles_l, int group_l, int xcd_stagger, const Epi& epi, char* smem) {
     constexpr bool MREG = epi_is_mreg<Epi>::value;
-    static_assert(MREG || epi_has_preload<Epi>::value || epi_has_produce<Epi>::value, "persistent tile: counted-store epilogues only");
+    static_assert(MREG || epi_has_preload<Epi>::value || epi_has_produce<Epi>::value || epi_has_hl<Epi>::value, "persistent tile: counted-store epilogues only");
+    constexpr bool LN = epi_is_ln<Epi>::value;   // LayerNorm folded into this (consuming) GEMM's epilogue
+    constexpr bool HL = epi_has_hl<Epi>::value;  // bf16 hi / lo residual stream
     constexpr bool F16 = epi_is_f16<Epi>::value;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,18 +156,30 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
     // FIRST K tile into 1-KiB slots behind the ring: a register load in the epilogue would be the YOUNGEST entry of the
     // in-order vmcnt queue, and waiting for it would drain the five half-tiles in flight for the next tile.
     // One piece per vector: lanes 0-15 carry the wave's 64 columns (16 B each), the other lanes re-read the same bytes.
-    constexpr int NC = epi_has_preload<Epi>::value ? 2 : 1;
+    // LN consumers: piece 0 = b' and the column sums cs of the wave's features (the two arrays sit cs_off floats apart), piece 1 =
+    // the row constants (rstd, -mu * rstd) of the wave's activation rows (8 B per row).
+    constexpr int NC = (epi_has_preload<Epi>::value || HL || LN) ? 2 : 1;
     char* cbuf = smem + G256_LDS_BYTES + wave * 2048;
-    auto issue_consts = [&](long rr) {
+    auto issue_consts = [&](long rr, long ll) {  // (r0, l0) of the tile the constants are for
         int l2 = tid & 63;
         asm volatile("" : "+v"(l2));
         if constexpr (MREG) {  // features sit on the L side: the wave's 128 features = lanes 0-31 x 16 B
-            glds16_saddr(epi.bias + rr + wl * 128, (uint32_t)(l2 & 31) * 16u, lds_addr(cbuf));
+            if constexpr (LN) {
+                glds16_saddr(epi.bias + ll + wl * 128, (uint32_t)(l2 & 31) * 16u + (uint32_t)(l2 >> 5) * (uint32_t)epi.cs_off * 4u, lds_addr(cbuf));
+                glds16_saddr(epi.rowstat + (rr + wr * 64 + epi.m_off) * 2, (uint32_t)(l2 & 31) * 16u, lds_addr(cbuf) + 1024);
+            } else {
+                glds16_saddr(epi.bias + ll + wl * 128, (uint32_t)(l2 & 31) * 16u, lds_addr(cbuf));
+            }
             return;
         }
         const uint32_t voff = (uint32_t)(l2 & 15) * 16u;
-        glds16_saddr(epi.bias + rr + wr * 64, voff, lds_addr(cbuf));
-        if constexpr (epi_has_preload<Epi>::value) glds16_saddr(epi.gamma + rr + wr * 64, voff, lds_addr(cbuf) + 1024);
+        if constexpr (LN) {
+            glds16_saddr(epi.bias + rr + wr * 64, voff + (uint32_t)((l2 >> 4) & 1) * (uint32_t)epi.cs_off * 4u, lds_addr(cbuf));
+            glds16_saddr(epi.rowstat + (ll + wl * 128) * 2, (uint32_t)l2 * 16u, lds_addr(cbuf) + 1024);
+        } else {
+            glds16_saddr(epi.bias + rr + wr * 64, voff, lds_addr(cbuf));
+            if constexpr (epi_has_preload<Epi>::value || HL) glds16_saddr(epi.gamma + rr + wr * 64, voff, lds_addr(cbuf) + 1024);
+        }
     };
 
     int slot0 = 0;  // ring slot of the current tile's half-tile 0 (0 or 4)
@@ -221,7 +241,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
         read_l(st + G256_HALF_BYTES);
         wait_vmcnt<4 + E>();
         __builtin_amdgcn_s_barrier();
-        if constexpr (FIRST) issue_consts(MREG ? l0 : r0);            // (NC more entries between the epilogue's stores and half-tile 5)
+        if constexpr (FIRST) issue_consts(r0, l0);            // (NC more entries between the epilogue's stores and half-tile 5)
         dma(Lk1, offL[0], st, 5);
         mma(rlo, 0, 0, first_tag);
         __builtin_amdgcn_s_barrier();
@@ -275,15 +295,31 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
             // lane group gq owns rows r0 + wr*64 + 16 gq .. +15 of feature l0 + wl*128 + 16 b + (lane & 15): 32 contiguous
             // bytes of the transposed output per fragment, stored straight from the accumulator layout
             const long m0 = r0 + wr * 64 + gq * 16;
+            [[maybe_unused]] float2 rs[16];  // LN: (rstd, -mu * rstd) of the lane group's 16 rows (the same for its 16 lanes: broadcast reads)
+            if constexpr (LN) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 t = *(const float4*)(cbuf + 1024 + (gq * 16 + 2 * i) * 8);
+                    rs[2 * i] = float2{t.x, t.y}; rs[2 * i + 1] = float2{t.z, t.w};
+                }
+            }
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int nl = b * 16 + (lane & 15);
                 const float bias = *(const float*)(cbuf + nl * 4);
                 float v[16];
+                if constexpr (LN) {
+                    const float cs = *(const float*)(cbuf + 512 + nl * 4);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[f * 4 + e] = fmaf(acc[f][b][e], rs[f * 4 + e].x, fmaf(rs[f * 4 + e].y, cs, bias));
+                } else {
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][b][e] + bias;
+                }
                 epi.template store16<FULL>(m0, l0 + wl * 128 + nl, v);
             }
         } else {
@@ -292,11 +328,16 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
         for (int f = 0; f < 4; ++f) {
             const float4 t = *(const float4*)(cbuf + (gq * 16 + 4 * f) * 4);
             ctx.bias[f * 4 + 0] = t.x; ctx.bias[f * 4 + 1] = t.y; ctx.bias[f * 4 + 2] = t.z; ctx.bias[f * 4 + 3] = t.w;
-            if constexpr (epi_has_preload<Epi>::value) {
-                const float4 u = *(const float4*)(cbuf + 1024 + (gq * 16 + 4 * f) * 4);
+            if constexpr (epi_has_preload<Epi>::value || HL || LN) {  // LayerScale gamma, or (LN) the column sums behind b'
+                const float4 u = *(const float4*)(cbuf + (LN ? 256 : 1024) + (gq * 16 + 4 * f) * 4);
                 ctx.gamma[f * 4 + 0] = u.x; ctx.gamma[f * 4 + 1] = u.y; ctx.gamma[f * 4 + 2] = u.z; ctx.gamma[f * 4 + 3] = u.w;
             }
         }
+        // LN: the row constants of this lane's row in accumulator block `blk` (rows 16 blk + (lane & 15) of the wave's 128)
+        auto row_consts = [&](int blk) {
+            if constexpr (LN) return *(const float2*)(cbuf + 1024 + (16 * blk + (lane & 15)) * 8);
+            else return float2{0.f, 0.f};
+        };
         if constexpr (epi_has_preload<Epi>::value) {
             // fp32 residual update x += gamma * (acc + bias): 16 rows x 64 columns of the wave's tile at a time are transposed
             // through LDS so one instruction covers 4 rows x 256 contiguous bytes; the x values of the NEXT 32 rows are
@@ -410,6 +451,95 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                 gst16_saddr(pbase, (uint32_t)lane * 16u, __builtin_bit_cast(u32x4, st4));
             }
 #endif
+        } else if constexpr (HL) {
+            // bf16 hi / lo residual stream: x = hi + lo (exact in fp32), x += gamma * (acc + bias), hi' = bf16(x), lo' = bf16(x - hi').
+            // Units of 16 rows x 64 columns are transposed through LDS as in the fp32 form; afterwards a lane owns 8 consecutive
+            // columns of rows r8 and r8 + 8 of the unit, so each of the unit's four loads and four stores covers 8 rows x 128
+            // contiguous bytes of one array.  The row sums of the new x (64 columns: 8 lanes, three DPP steps) are staged in the
+            // constants buffer (bias / gamma left it at the top of the epilogue) and leave as ONE 1-KiB store per wave:
+            // part[slot = column / 64][row][2] -- what cvx_rowstat_finalize turns into the next GEMM's (rstd, -mu * rstd).
+            constexpr int PITCH = 68;
+            float* stg = (float*)stg_base;
+            const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+            const uint32_t ldx = (uint32_t)epi.ldx;
+            const long mw = l0 + wl * 128, nw = r0 + wr * 64;      // first row / column of this wave's 128 x 64 part
+            const char* hw = (const char*)(epi.xh + mw * epi.ldx + nw);   // wave-uniform
+            const char* lw = (const char*)(epi.xl + mw * epi.ldx + nw);
+            const long mleft = epi.m_valid - mw;                   // rows of the part inside the problem (columns: always all)
+            uint32_t loff[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) loff[j] = ((uint32_t)(r8 + 8 * j) * ldx + (uint32_t)c8) * 2u;  // BYTES
+            u32x4 xv[3][4];  // [set][hi row A, lo row A, hi row B, lo row B]; unit u + 2 is requested before unit u is consumed
+            auto request = [&](u32x4 (&dst)[4], int u) {
+                const long ub = (long)(16 * u) * ldx * 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool ok = FULL || 16 * u + 8 * j + r8 < mleft;
+                    dst[2 * j] = ok ? __builtin_nontemporal_load((const u32x4*)(hw + ub + loff[j])) : u32x4{0u, 0u, 0u, 0u};
+                    dst[2 * j + 1] = ok ? __builtin_nontemporal_load((const u32x4*)(lw + ub + loff[j])) : u32x4{0u, 0u, 0u, 0u};
+                }
+            };
+            request(xv[0], 0);
+            request(xv[1], 1);
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[f][b][e] = ctx.gamma[f * 4 + e] * (acc[f][b][e] + ctx.bias[f * 4 + e]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u + 2 < 8) request(xv[(u + 2) % 3], u + 2);
+                __builtin_amdgcn_sched_barrier(0);  // (hipcc otherwise hoists all the requests to the top and spills)
+                const long ub = (long)(16 * u) * ldx * 2;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const f32x4 a = acc[f][u];
+                    *(float4*)(stg + (lane & 15) * PITCH + 16 * gq + 4 * f) = float4{a[0], a[1], a[2], a[3]};
+                }
+                float4 d[2][2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) d[j][h] = *(const float4*)(stg + (r8 + 8 * j) * PITCH + c8 + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x4 vh = xv[u % 3][2 * j], vl = xv[u % 3][2 * j + 1];
+                    const float dd[8] = {d[j][0].x, d[j][0].y, d[j][0].z, d[j][0].w, d[j][1].x, d[j][1].y, d[j][1].z, d[j][1].w};
+                    u32x4 nh, nl;
+                    float rs = 0.f, rq = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float x0 = (bflo(vh[k]) + bflo(vl[k])) + dd[2 * k];
+                        const float x1 = (bfhi(vh[k]) + bfhi(vl[k])) + dd[2 * k + 1];
+                        nh[k] = pack2bf(x0, x1);
+                        nl[k] = pack2bf(x0 - bflo(nh[k]), x1 - bfhi(nh[k]));
+                        rs += x0 + x1;
+                        rq = fmaf(x0, x0, fmaf(x1, x1, rq));
+                    }
+                    // across the 8 lanes that share the row: xor 1, xor 2 (quad permutes), then the other quad of the half row
+                    rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0xB1, 0xF, 0xF, true));
+                    rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0xB1, 0xF, 0xF, true));
+                    rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x4E, 0xF, 0xF, true));
+                    rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x4E, 0xF, 0xF, true));
+                    rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x141, 0xF, 0xF, true));
+                    rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x141, 0xF, 0xF, true));
+                    if ((lane & 7) == 0) *(float2*)(cbuf + (16 * u + 8 * j + r8) * 8) = float2{rs, rq};
+                    if (FULL || 16 * u + 8 * j + r8 < mleft) {
+                        gst16_saddr((void*)(hw + ub), loff[j], nh);        // the next GEMM reads hi: plain policy
+                        gst16_saddr_nt((void*)(lw + ub), loff[j], nl);     // lo is read once, a whole layer later: streaming
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const f32x4 st4 = *(const f32x4*)(cbuf + lane * 16);  // rows 2 lane, 2 lane + 1 of the wave's 128
+                const uintptr_t pp = (uintptr_t)(epi.part + (((r0 >> 6) + wr) * epi.part_rows + mw) * 2);  // (wave-uniform: into SGPRs)
+                char* pbase = (char*)(((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(pp >> 32)) << 32) |
+                                      (uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pp));
+                gst16_saddr(pbase, (uint32_t)lane * 16u, __builtin_bit_cast(u32x4, st4));  // (rows past m_valid: allocated, never read)
+            }
         } else {
             constexpr int O16 = Epi::OUT16, ROWB = 4 * O16 * 2, PITCHB = ROWB + 16, LPR = ROWB / 16, RPI = 64 / LPR;
             static_assert(32 * PITCHB <= 6144, "staging buffer of a wave");
@@ -436,7 +566,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][b][e];
                     uint32_t w[O16 / 2];
-                    epi.produce(ctx, v, w);
+                    epi.produce(ctx, v, w, row_consts(b));
                     char* ob = (char*)(outw + (long)(16 * b) * ldc);
                     if (FULL || (16 * b + (lane & 15) < mleft && ow + gq * 8 < (epi.n_valid >> Epi::OUT_SHIFT)))
                         gst16_saddr(ob, doff, u32x4{w[0], w[1], w[2], w[3]});
@@ -453,7 +583,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[f * 4 + e] = acc[f][2 * q + bb][e];
                     uint32_t w[O16 / 2];
-                    epi.produce(ctx, v, w);
+                    epi.produce(ctx, v, w, row_consts(2 * q + bb));
                     char* dst = stg + (16 * bb + (lane & 15)) * PITCHB + gq * (O16 * 2);
                     if constexpr (O16 == 16) {
                         *(uint4*)dst = uint4{w[0], w[1], w[2], w[3]};
@@ -481,7 +611,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
     };
 
     // ---- pipeline fill (first tile only): half-tiles 0..4 = K tile 0 and R-lo of K tile 1 ----
-    issue_consts(MREG ? l0 : r0);
+    issue_consts(r0, l0);
     dma((const char*)Rc, offR[0], smem, 0);
     dma((const char*)Lc, offL[0], smem, 1);
     dma((const char*)Rc, offR[1], smem, 2);

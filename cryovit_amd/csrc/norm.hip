@@ -10,14 +10,30 @@ namespace cvx {
 constexpr int LN_MAXJ = 8;  // float4 per lane: C <= 64*4*8 = 2048
 
 // One wave per row; the row lives in registers (two-pass mean / centred variance, fp32).
-__device__ __forceinline__ void ln_row_stats(const float* row, int C4, int lane, float4 (&v)[LN_MAXJ], float& mean,
+// The token stream is either one fp32 array or the bf16 (hi, lo) pair of the ViT path (x = hi + lo, exact in fp32)
+struct RowF32 {
+    const float* row;
+    __device__ __forceinline__ float4 ld4(int i) const { return *(const float4*)(row + 4 * i); }
+    __device__ __forceinline__ float ld1(int c) const { return row[c]; }
+};
+struct RowHL {
+    const uint16_t* hi; const uint16_t* lo;
+    __device__ __forceinline__ float4 ld4(int i) const {
+        const uint2 a = *(const uint2*)(hi + 4 * i), b = *(const uint2*)(lo + 4 * i);
+        return float4{bflo(a.x) + bflo(b.x), bfhi(a.x) + bfhi(b.x), bflo(a.y) + bflo(b.y), bfhi(a.y) + bfhi(b.y)};
+    }
+    __device__ __forceinline__ float ld1(int c) const { return bf2f(hi[c]) + bf2f(lo[c]); }
+};
+
+template <class Row>
+__device__ __forceinline__ void ln_row_stats(const Row& row, int C4, int lane, float4 (&v)[LN_MAXJ], float& mean,
                                              float& rstd, int C, float eps) {
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXJ; ++j) {
         const int i = lane + 64 * j;
         if (i < C4) {
-            v[j] = *(const float4*)(row + 4 * i);
+            v[j] = row.ld4(i);
             s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         }
     }
@@ -45,7 +61,7 @@ __global__ __launch_bounds__(256) void k_layernorm_bf16_v4(const float* __restri
     const int C4 = C >> 2;
     float4 v[LN_MAXJ];
     float mean, rstd;
-    ln_row_stats(x + row * ldx, C4, lane, v, mean, rstd, C, eps);
+    ln_row_stats(RowF32{x + row * ldx}, C4, lane, v, mean, rstd, C, eps);
 #pragma unroll
     for (int j = 0; j < LN_MAXJ; ++j) {
         const int i = lane + 64 * j;
@@ -193,7 +209,8 @@ constexpr int FN_TOK = 64, FN_CH = 256, FN_PITCH = FN_TOK + 8;  // pitch in half
 // contraction, so the two fp16 copies hold bit-identical values (the head gives the same result from the file as in HBM).
 __device__ __forceinline__ float ln_out(float x, float mean, float rstd, float w, float b) { return fmaf((x - mean) * rstd, w, b); }
 
-__global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+template <bool HL>  // HL: x = (xh, xl) bf16 pair (xl passed behind x), ldx in elements of either array
+__global__ __launch_bounds__(256) void k_final_norm(const void* __restrict__ x, const void* __restrict__ xlo, long ldx, const float* __restrict__ w,
                                                     const float* __restrict__ b, float eps, int ntp, int tok0, int npatch,
                                                     int C, _Float16* __restrict__ f16, long d_total, long d0,
                                                     uint16_t* __restrict__ cl, float* __restrict__ f32) {
@@ -203,13 +220,17 @@ __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x,
     const int slice = blockIdx.y, p0 = blockIdx.x * FN_TOK;
     const int ntile = min(FN_TOK, npatch - p0);
     const int C4 = C >> 2;
-    const float* xs = x + ((long)slice * ntp + tok0 + p0) * ldx;
+    const long row0 = (long)slice * ntp + tok0 + p0;
+    auto row_of = [&](int t) {
+        if constexpr (HL) return RowHL{(const uint16_t*)x + (row0 + t) * ldx, (const uint16_t*)xlo + (row0 + t) * ldx};
+        else return RowF32{(const float*)x + (row0 + t) * ldx};
+    };
 
     // phase 1: statistics (and the channels-last fp16 copy) -- one wave per token, 16 tokens per wave
     for (int t = wave; t < ntile; t += 4) {
         float4 v[LN_MAXJ];
         float mean, rstd;
-        ln_row_stats(xs + (long)t * ldx, C4, lane, v, mean, rstd, C, eps);
+        ln_row_stats(row_of(t), C4, lane, v, mean, rstd, C, eps);
         if (lane == 0) { s_mean[t] = mean; s_rstd[t] = rstd; }
         if (f32) {  // x_norm_patchtokens [slice][p][C] in fp32 (the encoder-protocol output)
             float* orow = f32 + ((long)slice * npatch + p0 + t) * C;
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(256) void k_final_norm(const float* __restrict__ x,
         if (tid < nch) {
             const float ww = w[c0 + tid], bb = b[c0 + tid];
             for (int t = 0; t < ntile; ++t) {
-                const float val = ln_out(xs[(long)t * ldx + c0 + tid], s_mean[t], s_rstd[t], ww, bb);
+                const float val = ln_out(row_of(t).ld1(c0 + tid), s_mean[t], s_rstd[t], ww, bb);
                 tile[tid * FN_PITCH + t] = __builtin_bit_cast(_Float16, f2h(val));
             }
         }
@@ -416,6 +437,80 @@ __global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x
     for (; v < v1; v += vstride) *(uint4*)(out + v * C + co) = norm(ld_stream16(x + v * C + co));
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The ViT's residual stream as a bf16 (hi, lo) pair with the LayerNorm folded into the consuming GEMMs.
+// ---------------------------------------------------------------------------------------------------
+// fp32 rows -> hi = bf16(x), lo = bf16(x - hi) and the row constants (rstd, -mean * rstd) of the FIRST LayerNorm: once per slice
+// batch, behind the patch-embedding GEMM (every later split and every later statistic comes out of a residual GEMM's epilogue).
+// One wave per row, 8 consecutive channels per lane and step (16-B stores); two-pass variance on the registers.
+__global__ __launch_bounds__(256) void k_split_stream(const float* __restrict__ x, long ldx, uint16_t* __restrict__ xh, uint16_t* __restrict__ xl,
+                                                      long ld, float* __restrict__ rowstat, long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int C8 = C >> 3;
+    const float* xr = x + row * ldx;
+    f32x4 v[LN_MAXJ8][2];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < C8) {
+            v[j][0] = *(const f32x4*)(xr + 8 * i);
+            v[j][1] = *(const f32x4*)(xr + 8 * i + 4);
+            s += ((v[j][0].x + v[j][0].y) + (v[j][0].z + v[j][0].w)) + ((v[j][1].x + v[j][1].y) + (v[j][1].z + v[j][1].w));
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXJ8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < C8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float a0 = v[j][h].x - mean, a1 = v[j][h].y - mean, a2 = v[j][h].z - mean, a3 = v[j][h].w - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            uint4 oh, ol;
+            uint32_t* ph = &oh.x;
+            uint32_t* pl = &ol.x;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float x0 = v[j][h][2 * k], x1 = v[j][h][2 * k + 1];
+                    const uint32_t hw = pack2bf(x0, x1);
+                    ph[2 * h + k] = hw;
+                    pl[2 * h + k] = pack2bf(x0 - bflo(hw), x1 - bfhi(hw));
+                }
+            *(uint4*)(xh + row * ld + 8 * i) = oh;
+            *(uint4*)(xl + row * ld + 8 * i) = ol;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0) *(float2*)(rowstat + 2 * row) = float2{rstd, -mean * rstd};
+}
+
+// part[slot][part_rows][2] (sum, sum of squares of a row over 64 columns, written by the hi/lo residual epilogue) ->
+// rowstat[row] = (rstd, -mean * rstd).  Fixed order, double accumulation: 24 partials of fp32 sums lose nothing further.
+__global__ __launch_bounds__(256) void k_rowstat_finalize(const float* __restrict__ part, int nslot, long part_rows, float* __restrict__ rowstat,
+                                                          long rows, float inv_c, float eps) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nslot; ++k) {
+        const float2 p = *(const float2*)(part + ((long)k * part_rows + row) * 2);
+        s += (double)p.x;
+        q += (double)p.y;
+    }
+    const double mean = s * (double)inv_c;
+    double var = q * (double)inv_c - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    *(float2*)(rowstat + 2 * row) = float2{rstd, -(float)mean * rstd};
+}
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -458,8 +553,40 @@ extern "C" int cvx_final_norm_features(const float* x, long ldx, const float* w,
     if (C % 4 || C > 64 * 4 * LN_MAXJ || ldx % 4) return cvx_fail("final_norm: C%4==0, C<=2048, ldx%4==0 required");
     const int npatch = hp * wp;
     dim3 grid((npatch + FN_TOK - 1) / FN_TOK, slices);
-    hipLaunchKernelGGL(k_final_norm, grid, dim3(256), 0, st, x, ldx, w, b, eps, ntp, tok0, npatch, C, (_Float16*)feats_f16,
+    hipLaunchKernelGGL(k_final_norm<false>, grid, dim3(256), 0, st, (const void*)x, (const void*)nullptr, ldx, w, b, eps, ntp, tok0, npatch, C,
+                       (_Float16*)feats_f16, d_total, d0, (uint16_t*)feats_cl, tokens_f32);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_final_norm_features_hl(const void* xh, const void* xl, long ld, const float* w, const float* b, float eps, int slices,
+                                          int ntp, int tok0, int hp, int wp, int C, void* feats_f16, long d_total, long d0,
+                                          void* feats_cl, float* tokens_f32, hipStream_t st) {
+    if (slices <= 0) return 0;
+    if (!xh || !xl) return cvx_fail("final_norm_hl: null stream");
+    if (C % 4 || C > 64 * 4 * LN_MAXJ || ld % 4) return cvx_fail("final_norm_hl: C%4==0, C<=2048, ld%4==0 required");
+    const int npatch = hp * wp;
+    dim3 grid((npatch + FN_TOK - 1) / FN_TOK, slices);
+    hipLaunchKernelGGL(k_final_norm<true>, grid, dim3(256), 0, st, xh, xl, ld, w, b, eps, ntp, tok0, npatch, C, (_Float16*)feats_f16,
                        d_total, d0, (uint16_t*)feats_cl, tokens_f32);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_split_stream(const float* x, long ldx, void* xh, void* xl, long ld, float* rowstat, long rows, int C, float eps,
+                                hipStream_t st) {
+    if (rows <= 0) return 0;
+    if (!x || !xh || !xl || !rowstat) return cvx_fail("split_stream: null pointer");
+    if (C % 8 || C > 64 * 8 * LN_MAXJ8 || ldx % 4 || ld % 8) return cvx_fail("split_stream: C%8==0, C<=2048, ldx%4==0, ld%8==0 required");
+    hipLaunchKernelGGL(k_split_stream, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, (uint16_t*)xh, (uint16_t*)xl, ld, rowstat, rows,
+                       C, eps);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_rowstat_finalize(const float* part, int nslot, long part_rows, float* rowstat, long rows, int C, float eps, hipStream_t st) {
+    if (rows <= 0) return 0;
+    if (!part || !rowstat) return cvx_fail("rowstat_finalize: null pointer");
+    if (nslot <= 0 || nslot * 64 != C || rows > part_rows) return cvx_fail("rowstat_finalize: nslot must be C / 64 and rows <= part_rows");
+    hipLaunchKernelGGL(k_rowstat_finalize, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, part, nslot, part_rows, rowstat, rows,
+                       1.0f / (float)C, eps);
     return cvx_check_launch();
 }
 
@@ -481,6 +608,7 @@ static int groupnorm_impl(const void* x, const float* w, const float* b, void* o
     const int vstride = 256 / cpt;
     long vpb_stat = std::max<long>(64, 8L * vstride);           // >= 8 voxels per thread
     long nstat = (nvox + vpb_stat - 1) / vpb_stat;
+    if (C / G >= CVX_GN_BLOCKS / 2) return cvx_fail("groupnorm: C / G must be < CVX_GN_BLOCKS / 2 (the 2C coefficients sit behind the block partials)");
     const long cap = CVX_GN_BLOCKS - C / G;
     if (nstat > cap) { nstat = cap; vpb_stat = (nvox + nstat - 1) / nstat; nstat = (nvox + vpb_stat - 1) / vpb_stat; }
     float* partials = stats + 2 * G;

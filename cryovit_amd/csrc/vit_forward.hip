@@ -19,6 +19,53 @@ static cvx_gemm_desc gemm_base(int epi, const void* a, long lda, const void* w, 
 }
 static long rup(long x, long m) { return (x + m - 1) / m * m; }
 
+// The product path: the residual stream lives as a bf16 (hi, lo) pair, `hi` IS the A operand of the qk / V^T / FFN-in GEMMs, whose
+// epilogues apply the LayerNorm from per-row constants (rstd, -mean * rstd); those come out of the previous residual GEMM's
+// epilogue as 64-column partial sums (cvx_rowstat_finalize: one ~5-us launch).  No LayerNorm pass, no xn buffer.
+static int vit_blocks_folded(const cvx_vit_desc* v, const cvx_vit_ws* ws, int b, int hp, int wp, int nt, int ntp, int kp, void* feats_f16,
+                             long d_total, long d0, void* feats_cl, float* tokens_f32, hipStream_t st) {
+    const int C = v->dim, tok0 = 1 + v->n_reg;
+    const long M = (long)b * ntp;
+    const long c128 = rup(C, 128), c2 = rup(2L * C, 128);
+    const long rows = rup(M, 256) + 256;  // allocation contract of cvx_vit_ws
+    if (!ws->xh || !ws->xl || !ws->stat_part || !ws->rowstat) return cvx_fail("vit_encode: ln_fold needs xh, xl, stat_part and rowstat workspaces");
+    if (C % 64) return cvx_fail("vit_encode: ln_fold needs dim % 64 == 0");
+    CVX_TRY(cvx_split_stream((const float*)ws->x, C, ws->xh, ws->xl, C, ws->rowstat, M, C, v->ln_eps, st));
+    auto resid = [&](const void* a, long lda, const void* w, long kpad, const float* bias, const float* gamma) {
+        cvx_gemm_desc d = gemm_base(CVX_EPI_RESID_HL, a, lda, w, kpad, M, C, c128, kpad, ws->xh, C, bias);
+        d.gamma = gamma; d.out2 = ws->xl; d.stat_part = ws->stat_part; d.stat_rows = rows;
+        return cvx_gemm_bf16(&d, st);
+    };
+    for (int i = 0; i < v->depth; ++i) {
+        const cvx_vit_layer* L = &v->layers[i];
+        {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_BF16, ws->xh, C, L->qk_w, C, M, 2L * C, c2, C, ws->qk, 2L * C, L->qk_b);
+            d.ln_rowstat = ws->rowstat;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        {
+            cvx_gemm_desc d = gemm_base(CVX_EPI_VT, ws->xh, C, L->v_w, C, M, C, c128, C, ws->vt, 0, L->v_b);
+            d.heads = v->heads; d.ntp = ntp; d.kp = kp; d.ln_rowstat = ws->rowstat;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        CVX_TRY(cvx_attention_bf16(ws->qk, 2L * C, ws->vt, ws->ao, C, b, v->heads, nt, ntp, kp, st));
+        CVX_TRY(resid(ws->ao, C, L->proj_w, C, L->proj_b, L->ls1));
+        CVX_TRY(cvx_rowstat_finalize(ws->stat_part, C / 64, rows, ws->rowstat, M, C, v->ln_eps, st));
+        {
+            const long n1 = v->ffn_swiglu ? 2L * v->hid_pad : (long)v->hid_pad;
+            cvx_gemm_desc d = gemm_base(v->ffn_swiglu ? CVX_EPI_SWIGLU : CVX_EPI_BF16_GELU, ws->xh, C, L->ffn1_w, C, M, n1, n1, C, ws->hid,
+                                        v->hid_pad, L->ffn1_b);
+            d.ln_rowstat = ws->rowstat;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+        }
+        CVX_TRY(resid(ws->hid, v->hid_pad, L->ffn2_w, v->hid_pad, L->ffn2_b, L->ls2));
+        if (i + 1 < v->depth)  // (the final LayerNorm computes its own statistics from the rows it reads)
+            CVX_TRY(cvx_rowstat_finalize(ws->stat_part, C / 64, rows, ws->rowstat, M, C, v->ln_eps, st));
+    }
+    return cvx_final_norm_features_hl(ws->xh, ws->xl, C, v->norm_w, v->norm_b, v->ln_eps, b, ntp, tok0, hp, wp, C, feats_f16, d_total, d0,
+                                      feats_cl, tokens_f32, st);
+}
+
 extern "C" int cvx_vit_encode(const cvx_vit_desc* v, const cvx_vit_ws* ws, int b, int hp, int wp, const void* patches, long patches_ld,
                               const void* pe_w, const float* pos, const float* cls_pos0, void* feats_f16, long d_total, long d0,
                               void* feats_cl, float* tokens_f32, hipStream_t st) {
@@ -35,6 +82,7 @@ extern "C" int cvx_vit_encode(const cvx_vit_desc* v, const cvx_vit_ws* ws, int b
         d.pos = pos; d.ldpos = C; d.npatch = npatch; d.ntp = ntp; d.tok0 = tok0;
         CVX_TRY(cvx_gemm_bf16(&d, st));
     }
+    if (v->ln_fold) return vit_blocks_folded(v, ws, b, hp, wp, nt, ntp, kp, feats_f16, d_total, d0, feats_cl, tokens_f32, st);
     for (int i = 0; i < v->depth; ++i) {
         const cvx_vit_layer* L = &v->layers[i];
         CVX_TRY(cvx_layernorm_bf16((const float*)ws->x, C, L->ln1_w, L->ln1_b, ws->xn, C, M, C, v->ln_eps, st));

@@ -70,12 +70,22 @@ def call(dev: torch.device, what: str, fn, *args) -> None:
 
 
 def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: torch.Tensor, *, m: int, n: int,
-         gamma=None, pos=None, npatch=0, ntp=0, tok0=0, heads=0, kp=0, H=0, W=0, cout=0, act=0, ldc=None, convt_up_z=0) -> None:
+         gamma=None, pos=None, npatch=0, ntp=0, tok0=0, heads=0, kp=0, H=0, W=0, cout=0, act=0, ldc=None, convt_up_z=0,
+         ln_rowstat=None, out2=None, stat_part=None) -> None:
     """C = A W^T with a fused epilogue.  a: bf16 [M_alloc, lda]; w: bf16 [n_pad, k_pad] (packed).  fp16 operands (both a and
-    w) select the fp16 MFMA and fp16 outputs (plain / GELU / ConvT epilogues: the segmentation head)."""
-    dev = _dev_check(a, w, out, bias, gamma, pos)
+    w) select the fp16 MFMA and fp16 outputs (plain / GELU / ConvT epilogues: the segmentation head).
+    ln_rowstat (fp32 [rows, 2]): LayerNorm folded into the GEMM -- bias is then fp32 [2, n_pad] (b' | column sums of the packed
+    weight).  EPI_RESID_HL: out / out2 = the bf16 hi / lo halves of the residual stream, stat_part fp32 [n_pad/64, rows, 2]."""
+    dev = _dev_check(a, w, out, bias, gamma, pos, ln_rowstat, out2, stat_part)
     assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and bias.dtype == torch.float32
-    assert a.stride(-1) == 1 and w.is_contiguous() and bias.numel() >= w.shape[0]
+    assert a.stride(-1) == 1 and w.is_contiguous() and bias.numel() >= w.shape[0] * (2 if ln_rowstat is not None else 1)
+    if ln_rowstat is not None and (ln_rowstat.dtype != torch.float32 or ln_rowstat.numel() < 2 * m):
+        raise _lib.CvxError("gemm: ln_rowstat must be fp32 with >= 2*m elements")
+    if epilogue == _lib.EPI_RESID_HL:
+        if out2 is None or stat_part is None or out.dtype != torch.bfloat16 or out2.dtype != torch.bfloat16 or stat_part.dim() != 3:
+            raise _lib.CvxError("gemm: EPI_RESID_HL needs bf16 out / out2 and stat_part fp32 [n_pad/64, rows, 2]")
+        if stat_part.shape[0] * 64 < w.shape[0] or stat_part.shape[1] < round_up(m, 256) or out2.stride(0) != out.stride(0):
+            raise _lib.CvxError("gemm: stat_part too small or hi / lo leading dimensions differ")
     d = GemmDesc()
     d.epilogue = epilogue
     d.a, d.lda = a.data_ptr(), a.stride(0)
@@ -88,6 +98,8 @@ def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bia
     d.npatch, d.ntp, d.tok0, d.heads, d.kp = npatch, ntp, tok0, heads, kp
     d.H, d.W, d.cout, d.act = H, W, cout, act
     d.convt_up_z = convt_up_z
+    d.ln_rowstat, d.out2, d.stat_part = _p(ln_rowstat), _p(out2), _p(stat_part)
+    d.stat_rows = stat_part.shape[1] if stat_part is not None else 0
     d.dtype = _lib.DTYPE_F16 if a.dtype == torch.float16 else _lib.DTYPE_BF16
     call(dev, "cvx_gemm_bf16", _lib.load().cvx_gemm_bf16, C.byref(d))
 
@@ -161,6 +173,30 @@ def final_norm_features(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: 
     dev = _dev_check(x, w, b, feats_f16, feats_cl, tokens_f32)
     call(dev, "cvx_final_norm_features", _lib.load().cvx_final_norm_features, x.data_ptr(), x.stride(0), w.data_ptr(),
          b.data_ptr(), eps, slices, ntp, tok0, hp, wp, Cdim, _p(feats_f16), d_total, d0, _p(feats_cl), _p(tokens_f32))
+
+
+def final_norm_features_hl(xh: torch.Tensor, xl: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, *, slices: int, ntp: int,
+                           tok0: int, hp: int, wp: int, Cdim: int, feats_f16, d_total: int, d0: int, feats_cl, tokens_f32=None) -> None:
+    dev = _dev_check(xh, xl, w, b, feats_f16, feats_cl, tokens_f32)
+    assert xh.dtype == xl.dtype == torch.bfloat16 and xh.stride(0) == xl.stride(0)
+    call(dev, "cvx_final_norm_features_hl", _lib.load().cvx_final_norm_features_hl, xh.data_ptr(), xl.data_ptr(), xh.stride(0),
+         w.data_ptr(), b.data_ptr(), eps, slices, ntp, tok0, hp, wp, Cdim, _p(feats_f16), d_total, d0, _p(feats_cl), _p(tokens_f32))
+
+
+def split_stream(x: torch.Tensor, xh: torch.Tensor, xl: torch.Tensor, rowstat: torch.Tensor, *, rows: int, Cdim: int, eps: float) -> None:
+    """fp32 rows -> bf16 (hi, lo) pair + LayerNorm row constants (rstd, -mean*rstd)."""
+    dev = _dev_check(x, xh, xl, rowstat)
+    assert x.dtype == torch.float32 and xh.dtype == xl.dtype == torch.bfloat16 and rowstat.dtype == torch.float32
+    assert xh.stride(0) == xl.stride(0) and min(x.shape[0], xh.shape[0], xl.shape[0]) >= rows and rowstat.numel() >= 2 * rows
+    call(dev, "cvx_split_stream", _lib.load().cvx_split_stream, x.data_ptr(), x.stride(0), xh.data_ptr(), xl.data_ptr(), xh.stride(0),
+         rowstat.data_ptr(), rows, Cdim, eps)
+
+
+def rowstat_finalize(stat_part: torch.Tensor, rowstat: torch.Tensor, *, rows: int, Cdim: int, eps: float) -> None:
+    dev = _dev_check(stat_part, rowstat)
+    assert stat_part.dtype == rowstat.dtype == torch.float32 and stat_part.dim() == 3 and rowstat.numel() >= 2 * rows
+    call(dev, "cvx_rowstat_finalize", _lib.load().cvx_rowstat_finalize, stat_part.data_ptr(), Cdim // 64, stat_part.shape[1],
+         rowstat.data_ptr(), rows, Cdim, eps)
 
 
 def im2col_patches(x: torch.Tensor, out: torch.Tensor) -> None:

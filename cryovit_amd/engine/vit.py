@@ -6,8 +6,12 @@ resize of ``/root/reference/src/cryovit/datasets/vit_dataset.py:117-123`` and th
 ``run/dino_features.py:59-61``.  Algorithm: SURVEY.md App. A.
 
 Data layout in HBM (b slices, C channels, NT = hp*wp+1+n_reg tokens, NTP = NT rounded up to 8):
-  x      fp32 [b*NTP (+pad)][C]   residual stream (row = slice*NTP + token; rows NT..NTP-1 are finite padding)
-  xn     bf16 [..][C]             LayerNorm output = GEMM A operand
+  xh, xl bf16 [b*NTP (+pad)][C]   residual stream as a bf16 PAIR x = hi + lo (row = slice*NTP + token; rows NT..NTP-1 are
+                                  finite padding).  hi = bf16(x) IS the A operand of the qk / V^T / FFN-in GEMMs: the LayerNorm
+                                  gain is folded into their weights, its normalisation into their epilogues
+  part   fp32 [C/64][..][2]       partial row sums written by the residual GEMMs' epilogues
+  rowst  fp32 [..][2]             (rstd, -mean*rstd) per row
+  (fold_ln=False keeps the round-2 plan: x fp32 [..][C] + xn bf16 [..][C] = LayerNorm output, separate LayerNorm launches)
   qk     bf16 [..][2C]            Q (pre-scaled by head_dim^-0.5 * log2 e) | K, token-major
   vt     bf16 [b][heads][64][KP]  V transposed per head (KP = NT rounded up to 64), written by the V GEMM epilogue
   ao     bf16 [..][C]             attention output
@@ -22,7 +26,7 @@ from dataclasses import dataclass
 import torch
 import torch.nn.functional as F
 
-from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU, EPI_PATCH, EPI_RESID, EPI_SWIGLU, EPI_VT
+from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU, EPI_PATCH, EPI_RESID, EPI_RESID_HL, EPI_SWIGLU, EPI_VT
 from cryovit_amd.engine import ops
 from cryovit_amd.engine.ops import alloc_rows, round_up
 
@@ -117,11 +121,12 @@ def interpolate_pos_embed(cfg: VitConfig, pos_embed: torch.Tensor, hp: int, wp: 
 class VitEngine:
     """Holds packed device weights and per-shape workspaces; ``features()`` runs one slice batch."""
 
-    def __init__(self, cfg: VitConfig, state_dict: dict, device="cuda:0"):
+    def __init__(self, cfg: VitConfig, state_dict: dict, device="cuda:0", fold_ln: bool = True):
         if not torch.cuda.is_available():
             raise ops._lib.CvxError("VitEngine needs a HIP device (no CPU fallback)")
         ops._lib.load()
         self.cfg, self.device = cfg, ops.norm_device(device)
+        self.fold_ln = bool(fold_ln)  # False: the round-2 plan (fp32 stream + LayerNorm launches), kept for A/B runs
         self._pos_src = state_dict["pos_embed"].detach().float().cpu()
         self._cls = state_dict["cls_token"].detach().float().cpu().reshape(-1)
         self._ws = {}
@@ -153,21 +158,37 @@ class VitEngine:
         # head_dim^-0.5 * log2(e) folded into the Q rows in fp32 BEFORE the bf16 rounding: the attention kernel works in log2
         # units (p = exp2(s - m), no per-score multiply; oracle/dinov2.py::forward_features_bf16_storage mirrors the rounding point)
         scale = 64**-0.5 * math.log2(math.e)
+        fold = self.fold_ln
+
+        def ln_linear(wm, bias, gamma, beta, n_pad):
+            """(packed bf16 weight, fp32 bias tensor) of a linear layer that consumes LayerNorm(gamma, beta).  fold_ln: the gain goes
+            into the weight, W' = bf16(W * gamma) (ONE rounding), and the bias tensor becomes [2, n_pad] = b' = b + W beta (fp64
+            matvec) | cs[n] = sum_k W'[n][k] (of the ROUNDED weight: it multiplies -mean*rstd against the same products the MFMA
+            accumulates)."""
+            if not fold:
+                return _bf16_padded(wm, n_pad, wm.shape[1]), _f32_padded(bias, n_pad)
+            wq = _bf16_padded(wm * gamma[None, :], n_pad, wm.shape[1])
+            bc = torch.zeros(2, n_pad, dtype=torch.float32, device=wm.device)
+            bc[0, : wm.shape[0]] = (bias.double() + wm.double() @ beta.double()).float()
+            bc[1] = wq.double().sum(dim=1).float()
+            return wq, bc
+
         for i in range(cfg.depth):
             p = f"blocks.{i}."
             qkv_w, qkv_b = g(p + "attn.qkv.weight").clone(), g(p + "attn.qkv.bias").clone()
             qkv_w[:C] *= scale
             qkv_b[:C] *= scale
+            g1, b1, g2, b2 = g(p + "norm1.weight"), g(p + "norm1.bias"), g(p + "norm2.weight"), g(p + "norm2.bias")
+            qk_w, qk_b = ln_linear(qkv_w[: 2 * C], qkv_b[: 2 * C], g1, b1, round_up(2 * C, 128))
+            v_w, v_b = ln_linear(qkv_w[2 * C :], qkv_b[2 * C :], g1, b1, n128)
             blk = {
-                "ln1_w": up(g(p + "norm1.weight")), "ln1_b": up(g(p + "norm1.bias")),
-                "qk_w": up(_bf16_padded(qkv_w[: 2 * C], round_up(2 * C, 128), C)),
-                "qk_b": up(_f32_padded(qkv_b[: 2 * C], round_up(2 * C, 128))),
-                "v_w": up(_bf16_padded(qkv_w[2 * C :], n128, C)),
-                "v_b": up(_f32_padded(qkv_b[2 * C :], n128)),
+                "ln1_w": up(g1), "ln1_b": up(b1),
+                "qk_w": up(qk_w), "qk_b": up(qk_b),
+                "v_w": up(v_w), "v_b": up(v_b),
                 "proj_w": up(_bf16_padded(g(p + "attn.proj.weight"), n128, C)),
                 "proj_b": up(_f32_padded(g(p + "attn.proj.bias"), n128)),
                 "ls1": up(_f32_padded(g(p + "ls1.gamma"), n128)),
-                "ln2_w": up(g(p + "norm2.weight")), "ln2_b": up(g(p + "norm2.bias")),
+                "ln2_w": up(g2), "ln2_b": up(b2),
                 "ls2": up(_f32_padded(g(p + "ls2.gamma"), n128)),
             }
             Hd, Hp = cfg.ffn_hidden, self.hid_pad
@@ -179,13 +200,13 @@ class VitEngine:
                 # interleave in blocks of 8 so one lane's 16 accumulators are 8 gates + their 8 values (EpiSwiGLU)
                 inter_w = torch.stack([a_w.reshape(-1, 8, C), b_w.reshape(-1, 8, C)], dim=1).reshape(2 * Hp, C)
                 inter_b = torch.stack([a_b.reshape(-1, 8), b_b.reshape(-1, 8)], dim=1).reshape(2 * Hp)
-                blk["ffn1_w"] = up(_bf16_padded(inter_w, 2 * Hp, C))
-                blk["ffn1_b"] = up(inter_b)
+                f1_w, f1_b = ln_linear(inter_w, inter_b, g2, b2, 2 * Hp)
+                blk["ffn1_w"], blk["ffn1_b"] = up(f1_w), up(f1_b)
                 blk["ffn2_w"] = up(_bf16_padded(g(p + "mlp.w3.weight"), n128, Hp))
                 blk["ffn2_b"] = up(_f32_padded(g(p + "mlp.w3.bias"), n128))
             else:
-                blk["ffn1_w"] = up(_bf16_padded(g(p + "mlp.fc1.weight"), Hp, C))
-                blk["ffn1_b"] = up(_f32_padded(g(p + "mlp.fc1.bias"), Hp))
+                f1_w, f1_b = ln_linear(g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"), g2, b2, Hp)
+                blk["ffn1_w"], blk["ffn1_b"] = up(f1_w), up(f1_b)
                 blk["ffn2_w"] = up(_bf16_padded(g(p + "mlp.fc2.weight"), n128, Hp))
                 blk["ffn2_b"] = up(_f32_padded(g(p + "mlp.fc2.bias"), n128))
             blocks.append(blk)
@@ -232,13 +253,21 @@ class VitEngine:
         z = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         ws = {
             "ape": z(alloc_rows(b * hp * wp), 640),
-            "x": z(rows, C, dt=torch.float32),
-            "xn": z(rows, C),
             "qk": z(rows, 2 * C),
             "vt": z(b, cfg.heads, 64, kp),
             "ao": z(rows, C),
             "hid": z(rows, self.hid_pad),
         }
+        if self.fold_ln:
+            ws["xh"], ws["xl"] = z(rows, C), z(rows, C)
+            ws["part"] = z(C // 64, rows, 2, dt=torch.float32)
+            ws["rowstat"] = z(rows, 2, dt=torch.float32)
+            # fp32 staging of the embedded tokens (init + patch-embed GEMM -> split): dead before the first FFN, so it lives in
+            # the hidden-activation buffer when that is large enough (every DINOv2 variant: hid_pad >= 2.6 C)
+            ws["x"] = (ws["hid"].view(-1)[: rows * C * 2].view(torch.float32).view(rows, C) if self.hid_pad >= 2 * C
+                       else z(rows, C, dt=torch.float32))
+        else:
+            ws["x"], ws["xn"] = z(rows, C, dt=torch.float32), z(rows, C)
         # keep the two most recent shapes resident: a tomogram whose depth is not a multiple of the slice batch alternates
         # between the full batch and the remainder, and must not re-allocate and re-zero ~4 GB twice per tomogram
         while len(self._ws) >= 2:
@@ -282,7 +311,7 @@ class VitEngine:
                              "ffn1_b", "ffn2_w", "ffn2_b", "ls2"):
                     setattr(layers[i], name, blk[name].data_ptr())
             d = VitDesc(dim=self.cfg.dim, depth=self.cfg.depth, heads=self.cfg.heads, n_reg=self.cfg.n_reg,
-                        ffn_swiglu=int(self.cfg.ffn == "swiglu"), hid_pad=self.hid_pad, ln_eps=self.cfg.ln_eps,
+                        ffn_swiglu=int(self.cfg.ffn == "swiglu"), hid_pad=self.hid_pad, ln_eps=self.cfg.ln_eps, ln_fold=int(self.fold_ln),
                         pe_b=self.w["pe_b"].data_ptr(), reg=self.w["reg"].data_ptr(), norm_w=self.w["norm_w"].data_ptr(),
                         norm_b=self.w["norm_b"].data_ptr(), layers=layers)
             self._cdesc = (d, layers)
@@ -297,9 +326,10 @@ class VitEngine:
 
         ws = self._workspace(b, hp, wp)
         pos, cls_pos0 = self._pos_for(hp, wp)
-        cws = VitWs(x=ws["x"].data_ptr(), xn=ws["xn"].data_ptr(), qk=ws["qk"].data_ptr(), vt=ws["vt"].data_ptr(),
-                    ao=ws["ao"].data_ptr(), hid=ws["hid"].data_ptr())
         p = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        cws = VitWs(x=ws["x"].data_ptr(), xn=p(ws.get("xn")), qk=ws["qk"].data_ptr(), vt=ws["vt"].data_ptr(),
+                    ao=ws["ao"].data_ptr(), hid=ws["hid"].data_ptr(), xh=p(ws.get("xh")), xl=p(ws.get("xl")),
+                    stat_part=p(ws.get("part")), rowstat=p(ws.get("rowstat")))
         if ops._dev_check(ape, pe_w, feats_f16, feats_cl, tokens_f32, ws["x"]) != self.device:
             raise _lib.CvxError(f"encoder: operands live on {ape.device}, the engine on {self.device}")
         ops.call(self.device, "cvx_vit_encode", _lib.load().cvx_vit_encode, C.byref(self._c_desc()), C.byref(cws), b, hp, wp,
@@ -316,6 +346,27 @@ class VitEngine:
 
         ops.init_tokens(ws["x"], cls_pos0, w["reg"], n_reg=cfg.n_reg, slices=b, ntok=nt, ntp=ntp, Cdim=C)
         ops.gemm(EPI_PATCH, ape, pe_w, ws["x"], w["pe_b"], m=b * npatch, n=C, pos=pos, npatch=npatch, ntp=ntp, tok0=tok0)
+        if self.fold_ln:
+            rs = ws["rowstat"]
+            ops.split_stream(ws["x"], ws["xh"], ws["xl"], rs, rows=M, Cdim=C, eps=cfg.ln_eps)
+            for i, blk in enumerate(self.blocks):
+                ops.gemm(EPI_BF16, ws["xh"], blk["qk_w"], ws["qk"], blk["qk_b"], m=M, n=2 * C, ln_rowstat=rs)
+                ops.gemm(EPI_VT, ws["xh"], blk["v_w"], ws["vt"], blk["v_b"], m=M, n=C, heads=cfg.heads, ntp=ntp, kp=kp, ldc=0, ln_rowstat=rs)
+                ops.attention(ws["qk"], ws["vt"], ws["ao"], slices=b, heads=cfg.heads, ntok=nt, ntp=ntp, kp=kp)
+                ops.gemm(EPI_RESID_HL, ws["ao"], blk["proj_w"], ws["xh"], blk["proj_b"], m=M, n=C, gamma=blk["ls1"], out2=ws["xl"],
+                         stat_part=ws["part"])
+                ops.rowstat_finalize(ws["part"], rs, rows=M, Cdim=C, eps=cfg.ln_eps)
+                if cfg.ffn == "swiglu":
+                    ops.gemm(EPI_SWIGLU, ws["xh"], blk["ffn1_w"], ws["hid"], blk["ffn1_b"], m=M, n=2 * self.hid_pad, ln_rowstat=rs)
+                else:
+                    ops.gemm(EPI_BF16_GELU, ws["xh"], blk["ffn1_w"], ws["hid"], blk["ffn1_b"], m=M, n=self.hid_pad, ln_rowstat=rs)
+                ops.gemm(EPI_RESID_HL, ws["hid"], blk["ffn2_w"], ws["xh"], blk["ffn2_b"], m=M, n=C, gamma=blk["ls2"], out2=ws["xl"],
+                         stat_part=ws["part"])
+                if i + 1 < len(self.blocks):
+                    ops.rowstat_finalize(ws["part"], rs, rows=M, Cdim=C, eps=cfg.ln_eps)
+            ops.final_norm_features_hl(ws["xh"], ws["xl"], w["norm_w"], w["norm_b"], cfg.ln_eps, slices=b, ntp=ntp, tok0=tok0, hp=hp,
+                                       wp=wp, Cdim=C, feats_f16=feats_f16, d_total=d_total, d0=d0, feats_cl=feats_cl, tokens_f32=tokens_f32)
+            return
         for blk in self.blocks:
             ops.layernorm(ws["x"], blk["ln1_w"], blk["ln1_b"], ws["xn"], M, C, cfg.ln_eps)
             ops.gemm(EPI_BF16, ws["xn"], blk["qk_w"], ws["qk"], blk["qk_b"], m=M, n=2 * C)

@@ -64,7 +64,11 @@ enum cvx_epilogue {
     CVX_EPI_PATCH = 4,     /* out fp32 token stream: row slice*ntp+tok0+p = acc + bias + pos[1+p]     */
     CVX_EPI_VT = 5,        /* out bf16 V^T [slice][head][64][kp] = acc + bias   (for cvx_attention)   */
     CVX_EPI_CONVT = 6,     /* out bf16 [D][2H][2W][cout] pixel-shuffle of N = 4*cout, optional GELU   */
-    CVX_EPI_F32 = 7        /* out fp32 [M][ldc]       = gamma * (acc + bias)   (written, not accumulated)  */
+    CVX_EPI_F32 = 7,       /* out fp32 [M][ldc]       = gamma * (acc + bias)   (written, not accumulated)  */
+    CVX_EPI_RESID_HL = 8   /* the residual stream as a bf16 PAIR: x = hi + lo (out = hi, out2 = lo, both bf16 [M][ldc]);
+                              x += gamma * (acc + bias); hi = bf16(x), lo = bf16(x - hi); stat_part[n / 64][m] = (sum, sum of
+                              squares) of the new x over 64-column slots (N == n_pad, a multiple of 64).  hi is the next GEMM's A
+                              operand: see ln_rowstat                                                            */
 };
 
 enum { CVX_DTYPE_BF16 = 0, CVX_DTYPE_F16 = 1 };
@@ -85,6 +89,13 @@ typedef struct cvx_gemm_desc {
                                   and outputs (BF16, BF16_GELU and CONVT epilogues only: the segmentation head) */
     int convt_up_z;            /* CONVT: 0 = kernel/stride (1,2,2), N = 4*C_out (the head); 1 = (2,2,2), N = 8*C_out with
                                   n = ((iz*2+i)*2+j)*C_out + o, output [2D][2H][2W][C_out] (UNet3D upconv, unet3d.py:166-170) */
+    /* LayerNorm folded into the GEMM (BF16, BF16_GELU, SWIGLU, VT; bf16 operands): A = bf16(x) un-normalised (the hi array), W
+     * packed as bf16(W * ln_gamma), bias = fp32 [2][n_pad]: b' = b + W ln_beta, then cs[n] = sum_k W'[n][k];
+     * ln_rowstat = fp32 [M][2] = (rstd, -mean * rstd) per row (cvx_rowstat_finalize / cvx_split_stream).  The epilogue then
+     * starts from  rstd * acc + (-mean * rstd) * cs[n] + b'[n]  instead of acc + bias[n].  NULL: plain epilogue. */
+    const float* ln_rowstat;
+    /* RESID_HL: lo array, fp32 partial row sums [n_pad / 64][stat_rows][2], stat_rows >= M rounded up to 256 */
+    void* out2; float* stat_part; long stat_rows;
 } cvx_gemm_desc;
 
 int cvx_gemm_bf16(const cvx_gemm_desc* d, hipStream_t stream);
@@ -153,6 +164,21 @@ int cvx_init_tokens(float* x, long ldx, const float* cls_pos0, const float* reg,
 int cvx_final_norm_features(const float* x, long ldx, const float* w, const float* b, float eps, int slices,
                             int ntp, int tok0, int hp, int wp, int C, void* feats_f16, long d_total, long d0,
                             void* feats_cl, float* tokens_f32, hipStream_t stream);
+
+/* The ViT path keeps its residual stream as a PAIR of bf16 arrays, x = hi + lo (hi = bf16(x) doubles as the A operand of the
+ * next GEMM, which applies the LayerNorm in its epilogue: cvx_gemm_desc.ln_rowstat; lo = bf16(x - hi)).
+ * cvx_final_norm_features_hl: cvx_final_norm_features reading that pair (ld in elements of either array).
+ * cvx_split_stream: fp32 rows -> (hi, lo) and rowstat[row] = (rstd, -mean * rstd) of nn.LayerNorm(C, eps) over the row: the
+ *   hand-over from the patch-embedding GEMM (fp32) to the first block.
+ * cvx_rowstat_finalize: the partial row sums a CVX_EPI_RESID_HL GEMM left in stat_part[nslot = C / 64][part_rows][2] ->
+ *   rowstat[rows][2] for the next GEMM. */
+int cvx_final_norm_features_hl(const void* xh, const void* xl, long ld, const float* w, const float* b, float eps, int slices,
+                               int ntp, int tok0, int hp, int wp, int C, void* feats_f16, long d_total, long d0,
+                               void* feats_cl, float* tokens_f32, hipStream_t stream);
+int cvx_split_stream(const float* x, long ldx, void* xh, void* xl, long ld, float* rowstat, long rows, int C, float eps,
+                     hipStream_t stream);
+int cvx_rowstat_finalize(const float* part, int nslot, long part_rows, float* rowstat, long rows, int C, float eps,
+                         hipStream_t stream);
 
 /* im2col of already-resized 3-channel images x fp32 [b][3][Hi][Wi] (Hi, Wi multiples of 14) for the
  * encoder-protocol entry point forward_features(x) (run/dino_features.py:58): out bf16 [b*hp*wp][k_pad],
@@ -278,6 +304,10 @@ typedef struct cvx_vit_layer {
 typedef struct cvx_vit_desc {
     int dim, depth, heads, n_reg, ffn_swiglu, hid_pad;
     float ln_eps;
+    int ln_fold;                   /* 1 (the product path): LayerNorms folded into the qk / v / ffn1 GEMMs and the residual stream
+                                      kept as a bf16 (hi, lo) pair.  The layers then carry qk_w / v_w / ffn1_w = bf16(W * ln_gamma)
+                                      and qk_b / v_b / ffn1_b = fp32 [2][n_pad] (b' | column sums, see cvx_gemm_desc.ln_rowstat);
+                                      ln1_* / ln2_* are not read.  0: separate cvx_layernorm_bf16 passes over an fp32 stream */
     const float* pe_b;             /* fp32 [rup(C,128)] patch-embed bias */
     const float* reg;              /* fp32 [n_reg][C] register tokens */
     const float *norm_w, *norm_b;  /* final LayerNorm */
@@ -285,12 +315,18 @@ typedef struct cvx_vit_desc {
 } cvx_vit_desc;
 
 typedef struct cvx_vit_ws {        /* device workspaces, rows = rup(b*ntp,256)+256 (ntp = tokens per slice rounded up to 8) */
-    void* x;    /* fp32 [rows][C]        */
-    void* xn;   /* bf16 [rows][C]        */
+    void* x;    /* fp32 [rows][C]: the residual stream (ln_fold = 0); ln_fold = 1: staging of the embedded tokens only, dead
+                   after the split -- it may alias `hid` when hid_pad >= 2 C */
+    void* xn;   /* bf16 [rows][C]  LayerNorm output (ln_fold = 0 only; may be NULL otherwise) */
     void* qk;   /* bf16 [rows][2C]       */
     void* vt;   /* bf16 [b][heads][64][kp], zero-initialised once (kp = tokens rounded up to 64) */
     void* ao;   /* bf16 [rows][C], zero-initialised once */
     void* hid;  /* bf16 [rows][hid_pad]  */
+    /* ln_fold = 1: */
+    void* xh;   /* bf16 [rows][C]  hi half of the residual stream = A operand of the qk / v / ffn1 GEMMs */
+    void* xl;   /* bf16 [rows][C]  lo half */
+    float* stat_part; /* fp32 [C / 64][rows][2] partial row sums */
+    float* rowstat;   /* fp32 [rows][2] (rstd, -mean * rstd) */
 } cvx_vit_ws;
 
 /* patches: bf16 [rup(b*hp*wp,256)+256][patches_ld] from cvx_preprocess_patches (patches_ld = 256, pe_w = channel-summed

@@ -198,6 +198,74 @@ def forward_features_bf16_storage(cfg: VitCfg, sd: dict, x: torch.Tensor) -> dic
             "x_norm_patchtokens": t[:, 1 + cfg.n_reg :]}
 
 
+def split_hi_lo(t: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """The HIP path's residual-stream storage: hi = bf16(x), lo = bf16(x - hi); x is read back as hi + lo (exact in fp32)."""
+    hi = _bf(t)
+    return hi, _bf(t - hi)
+
+
+@torch.inference_mode()
+def forward_features_folded_storage(cfg: VitCfg, sd: dict, x: torch.Tensor) -> dict[str, torch.Tensor]:
+    """Second storage-plan emulation: the plan the HIP path SHIPS (round 3).  Exact (fp32) arithmetic, with
+      * the residual stream stored as a bf16 pair (hi, lo) after the patch embedding and after every residual update;
+      * every LayerNorm inside a block FOLDED into the linear layer that consumes it: the GEMM's A operand is hi = bf16(x)
+        un-normalised, its weight is W' = bf16(W * ln_gamma), and the normalisation is applied to the accumulator,
+        y = rstd * (hi W'^T) - mean * rstd * cs + b',  cs[n] = sum_k W'[n][k],  b' = b + W ln_beta;
+      * row statistics (mean, E[x^2] - mean^2) taken from the fp32 value of the stream BEFORE it is split;
+      * everything else as in ``forward_features_bf16_storage`` (q scale folded in log2 units, bf16 q/k/v, probabilities, attention
+        output and hidden activations).
+    The final LayerNorm reads hi + lo."""
+    b, _, H, W = x.shape
+    hp, wp = H // cfg.patch, W // cfg.patch
+    C, nh, hd = cfg.dim, cfg.heads, cfg.head_dim
+    t = F.conv2d(_bf(x), _bf(sd["patch_embed.proj.weight"]), sd["patch_embed.proj.bias"], stride=cfg.patch).flatten(2).transpose(1, 2)
+    t = torch.cat([sd["cls_token"].expand(b, -1, -1), t], dim=1) + interpolate_pos_embed(cfg, sd["pos_embed"], hp, wp)
+    t = torch.cat([t[:, :1], sd["register_tokens"].expand(b, -1, -1), t[:, 1:]], dim=1)
+    N = t.shape[1]
+
+    def stats(v):
+        mu = v.mean(-1, keepdim=True)
+        var = ((v * v).mean(-1, keepdim=True) - mu * mu).clamp_min(0.0)
+        rstd = torch.rsqrt(var + cfg.ln_eps)
+        return rstd, -mu * rstd
+
+    def ln_linear(hi, rs, gamma, beta, wm, bias):
+        wg = _bf(wm * gamma[None, :])
+        bp = (bias.double() + wm.double() @ beta.double()).float()
+        return rs[0] * (hi @ wg.t()) + rs[1] * wg.sum(1) + bp
+
+    rs = stats(t)
+    hi, lo = split_hi_lo(t)
+    for i in range(cfg.depth):
+        p = f"blocks.{i}."
+        w = sd[p + "attn.qkv.weight"].clone()
+        bias = sd[p + "attn.qkv.bias"].clone()
+        w[:C] *= hd**-0.5 * math.log2(math.e)
+        bias[:C] *= hd**-0.5 * math.log2(math.e)
+        qkv = _bf(ln_linear(hi, rs, sd[p + "norm1.weight"], sd[p + "norm1.bias"], w, bias)).reshape(b, N, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        sc = q @ k.transpose(-2, -1)
+        e = torch.exp2(sc - sc.amax(-1, keepdim=True))
+        a = (_bf(e) @ v) / e.sum(-1, keepdim=True)
+        a = _bf(a.transpose(1, 2).reshape(b, N, C))
+        t = (hi + lo) + sd[p + "ls1.gamma"] * F.linear(a, _bf(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
+        rs = stats(t)
+        hi, lo = split_hi_lo(t)
+        if cfg.ffn == "swiglu":
+            x1, x2 = ln_linear(hi, rs, sd[p + "norm2.weight"], sd[p + "norm2.bias"], sd[p + "mlp.w12.weight"], sd[p + "mlp.w12.bias"]).chunk(2, dim=-1)
+            mm = F.linear(_bf(F.silu(x1) * x2), _bf(sd[p + "mlp.w3.weight"]), sd[p + "mlp.w3.bias"])
+        else:
+            h1 = ln_linear(hi, rs, sd[p + "norm2.weight"], sd[p + "norm2.bias"], sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+            mm = F.linear(_bf(F.gelu(h1)), _bf(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
+        t = (hi + lo) + sd[p + "ls2.gamma"] * mm
+        rs = stats(t)
+        hi, lo = split_hi_lo(t)
+    pre = hi + lo
+    t = F.layer_norm(pre, (C,), sd["norm.weight"], sd["norm.bias"], cfg.ln_eps)
+    return {"x_prenorm": pre, "x_norm_clstoken": t[:, 0], "x_norm_regtokens": t[:, 1 : 1 + cfg.n_reg],
+            "x_norm_patchtokens": t[:, 1 + cfg.n_reg :]}
+
+
 @torch.inference_mode()
 def forward_features(cfg: VitCfg, sd: dict, x: torch.Tensor) -> dict[str, torch.Tensor]:
     """``[b,3,H',W'] fp32 -> {"x_norm_patchtokens": [b, hp*wp, C], ...}`` (App. A-4)."""

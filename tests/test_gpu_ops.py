@@ -259,6 +259,32 @@ def test_attention(gpu, nt, slices, heads, attn_variant):
     assert torch.all(got[:, nt:] == 0), "padding rows must not be written"
 
 
+@pytest.mark.parametrize("pad", [8, 24, 40])
+def test_attention_odd_leading_dimension(gpu, pad):
+    """ldqk NOT a multiple of 64 with a single-wave last query block (ntok % 128 in (0, 32]): the default kernel's lone-wave DMA
+    offsets assume a 128-byte-multiple K row pitch; such calls must take the general kernel and stay correct."""
+    from cryovit_amd.engine import ops
+
+    nt, slices, heads = 128 + 5, 2, 1
+    C = heads * 64
+    ntp, kp = ops.round_up(nt, 8), ops.round_up(nt, 64)
+    M, ld = slices * ntp, 2 * C + pad
+    q, k, v = rnd(slices, nt, heads, 64, seed=124) * 1.5, rnd(slices, nt, heads, 64, seed=125), rnd(slices, nt, heads, 64, seed=126)
+    qk = torch.randn(ops.alloc_rows(M), ld, generator=torch.Generator().manual_seed(127)).to(torch.bfloat16)
+    qkv = qk[:M].reshape(slices, ntp, ld)
+    qkv[:, :nt, :C] = bf(q * 0.125 * LOG2E).reshape(slices, nt, C)
+    qkv[:, :nt, C : 2 * C] = bf(k).reshape(slices, nt, C)
+    vt = torch.zeros(slices, heads, 64, kp, dtype=torch.bfloat16)
+    vt[..., :nt] = bf(v).permute(0, 2, 3, 1)
+    out = torch.zeros(ops.alloc_rows(M), C, dtype=torch.bfloat16, device=gpu)
+    ops.attention(qk.to(gpu), vt.to(gpu), out, slices=slices, heads=heads, ntok=nt, ntp=ntp, kp=kp)
+    qf, kf, vf = bf(q * 0.125 * LOG2E).float() / LOG2E, bf(k).float(), bf(v).float()
+    att = torch.softmax(torch.einsum("snhd,smhd->shnm", qf, kf), dim=-1)
+    ref = torch.einsum("shnm,smhd->snhd", att, vf).reshape(slices, nt, C)
+    got = out[:M].float().cpu().reshape(slices, ntp, C)
+    assert torch.allclose(got[:, :nt], ref, atol=2e-2, rtol=2e-2), float((got[:, :nt] - ref).abs().max())
+
+
 @pytest.mark.parametrize("spike", [4.0, 60.0, -60.0])
 @pytest.mark.parametrize("attn_variant", [0, 4, 6], indirect=True)
 def test_attention_forced_rescale(gpu, attn_variant, spike):
@@ -731,3 +757,211 @@ def test_gemm256_tail_split_vt_swiglu(gpu):
     ref = F.silu(h[:, :Hd]) * h[:, Hd:]
     assert torch.allclose(out[:M].float().cpu(), ref, atol=2e-2, rtol=1e-2)
     assert torch.all(out[M:] == 0)
+
+
+# ---- round 3: bf16 (hi, lo) residual stream + LayerNorm folded into the consuming GEMMs ------------------------------------------
+
+
+def _split(t):
+    hi = bf(t)
+    return hi, bf(t - hi.float())
+
+
+@pytest.mark.parametrize("rows,C", [(37, 128), (300, 384), (1032, 1536)])
+def test_split_stream(gpu, rows, C):
+    """fp32 rows -> hi = bf16(x), lo = bf16(x - hi) BIT-EXACT, row constants (rstd, -mean*rstd) of LayerNorm(eps 1e-6)."""
+    from cryovit_amd.engine import ops
+
+    x = rnd(rows, C, seed=301, scale=3.0) + 0.7
+    x[:, 5] *= 150.0  # an outlier channel
+    R = ops.alloc_rows(rows)
+    xh = torch.full((R, C), 7.0, dtype=torch.bfloat16, device=gpu)
+    xl = torch.full((R, C), 7.0, dtype=torch.bfloat16, device=gpu)
+    rs = torch.zeros(R, 2, device=gpu)
+    xd = torch.zeros(R, C, device=gpu)
+    xd[:rows] = x.to(gpu)
+    ops.split_stream(xd, xh, xl, rs, rows=rows, Cdim=C, eps=1e-6)
+    hi, lo = _split(x)
+    assert torch.equal(xh[:rows].cpu(), hi) and torch.equal(xl[:rows].cpu(), lo)
+    assert torch.all(xh[rows:].float() == 7.0) and torch.all(xl[rows:].float() == 7.0)
+    xd64 = x.double()
+    mu, var = xd64.mean(1), xd64.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-6)
+    got = rs[:rows].cpu().double()
+    assert torch.allclose(got[:, 0], rstd, rtol=2e-6, atol=0) and torch.allclose(got[:, 1], -mu * rstd, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 384, 256), (300, 128, 192), (2048, 1536, 512), (2311, 512, 256), (5000, 1536, 1536)])
+def test_gemm_resid_hl(gpu, M, N, K):
+    """CVX_EPI_RESID_HL: x = hi + lo; x += gamma * (acc + bias); hi', lo' = split(x); stat_part[n/64][m] = row sums of the new x
+    over 64-column slots.  Shapes cover the 128-wide tiles (M < 1024), the persistent 256 tile with interior tiles only (2048),
+    with a ragged last M tile (2311) and the main + tail split (5000 x 1536: 20 x 6 tiles)."""
+    from cryovit_amd._lib import EPI_RESID_HL
+    from cryovit_amd.engine import ops
+
+    a, w, b, g = rnd(M, K, seed=311), rnd(N, K, seed=312, scale=K**-0.5), rnd(N, seed=313), rnd(N, seed=314)
+    x0 = rnd(M, N, seed=315, scale=2.0)
+    x0[:, 3] *= 100.0
+    hi0, lo0 = _split(x0)
+    R = ops.alloc_rows(M)
+    xh = torch.full((R, N), 7.0, dtype=torch.bfloat16, device=gpu)
+    xl = torch.full((R, N), 7.0, dtype=torch.bfloat16, device=gpu)
+    xh[:M], xl[:M] = hi0.to(gpu), lo0.to(gpu)
+    part = torch.full((N // 64, R, 2), float("nan"), device=gpu)
+    ops.gemm(EPI_RESID_HL, padded_bf16(a, R, K, gpu), padded_bf16(w, N, K, gpu), xh, b.to(gpu), m=M, n=N, gamma=g.to(gpu), out2=xl, stat_part=part)
+    ref = (hi0.float() + lo0.float()).double() + g.double() * (bf(a).double() @ bf(w).double().T + b.double())
+    got_h, got_l = xh[:M].float().cpu(), xl[:M].float().cpu()
+    got = (got_h + got_l).double()
+    # the pair carries 16+ significant bits; the fp32 accumulation order of the MFMA differs from the CPU's
+    assert torch.allclose(got, ref, atol=2e-4, rtol=3e-5), float((got - ref).abs().max())
+    assert torch.equal(got_h, bf((got_h + got_l)).float()), "hi is not bf16(hi + lo)"
+    assert float((got_l.abs() - got_h.abs() * 2.0**-8).max()) <= 0, "lo is not the rounding remainder of hi"
+    assert torch.all(xh[M:].float() == 7.0) and torch.all(xl[M:].float() == 7.0), "rows beyond M were written"
+    p = part[:, :M].cpu().double()
+    assert torch.isfinite(p).all()
+    gs = got.reshape(M, N // 64, 64)
+    s_ref, q_ref = gs.sum(-1).t(), (gs * gs).sum(-1).t()
+    scale = gs.abs().sum(-1).t()
+    assert float(((p[..., 0] - s_ref).abs() / (scale + 1e-3)).max()) <= 2e-5  # (sums of x before the split vs of hi + lo)
+    assert torch.allclose(p[..., 1], q_ref, rtol=5e-5, atol=1e-4)
+    # the statistics kernel on those partials
+    rs = torch.zeros(R, 2, device=gpu)
+    ops.rowstat_finalize(part, rs, rows=M, Cdim=N, eps=1e-6)
+    mu, var = got.mean(1), got.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-6)
+    r = rs[:M].cpu().double()
+    assert torch.allclose(r[:, 0], rstd, rtol=2e-4) and torch.allclose(r[:, 1], -mu * rstd, rtol=2e-3, atol=2e-4)
+
+
+def _ln_fold_pack(w, bias, gamma, beta, n_pad, dev):
+    """bf16(W * gamma) and [2, n_pad] = (b + W beta | column sums of the rounded weight): VitEngine._pack's ln_linear."""
+    wq = torch.zeros(n_pad, w.shape[1], dtype=torch.bfloat16)
+    wq[: w.shape[0]] = bf(w * gamma[None, :])
+    bc = torch.zeros(2, n_pad)
+    bc[0, : w.shape[0]] = (bias.double() + w.double() @ beta.double()).float()
+    bc[1] = wq.double().sum(1).float()
+    return wq.to(dev), bc.to(dev)
+
+
+def _ln_ref(a, w, bias, gamma, beta, rs_dev, M):
+    """The folded form on the CPU from the SAME row constants the GPU read."""
+    rs = rs_dev[:M].cpu()
+    wq = bf(w * gamma[None, :]).float()
+    bp = (bias.double() + w.double() @ beta.double()).float()
+    return rs[:, :1] * (bf(a).float() @ wq.T) + rs[:, 1:] * wq.sum(1) + bp
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (1000, 192, 128), (2048, 1024, 256), (2311, 768, 384), (5000, 3072, 1536)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gemm_bf16_ln_fold(gpu, M, N, K, gelu):
+    """BF16 / BF16_GELU epilogue with the LayerNorm folded in: A = raw rows (outlier channel, non-zero mean), row constants from
+    cvx_split_stream, against (i) the folded arithmetic on the CPU and (ii) LayerNorm -> Linear in fp32."""
+    from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU
+    from cryovit_amd.engine import ops
+
+    x = rnd(M, K, seed=321, scale=1.5) + 0.3
+    x[:, 7] *= 40.0
+    w, bias = rnd(N, K, seed=322, scale=K**-0.5), rnd(N, seed=323)
+    gamma, beta = torch.exp(rnd(K, seed=324) * 0.5), rnd(K, seed=325, scale=0.2)
+    R = ops.alloc_rows(M)
+    xd = torch.zeros(R, K, device=gpu)
+    xd[:M] = x.to(gpu)
+    xh, xl, rs = torch.zeros(R, K, dtype=torch.bfloat16, device=gpu), torch.zeros(R, K, dtype=torch.bfloat16, device=gpu), torch.zeros(R, 2, device=gpu)
+    ops.split_stream(xd, xh, xl, rs, rows=M, Cdim=K, eps=1e-6)
+    n_pad = ops.round_up(N, 128)
+    wq, bc = _ln_fold_pack(w, bias, gamma, beta, n_pad, gpu)
+    out = torch.full((R, N), 7.0, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_BF16_GELU if gelu else EPI_BF16, xh, wq, out, bc, m=M, n=N, ln_rowstat=rs)
+    ref = _ln_ref(x, w, bias, gamma, beta, rs, M)
+    full = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-6), w, bias)
+    if gelu:
+        ref, full = F.gelu(ref), F.gelu(full)
+    got = out[:M].float().cpu()
+    assert torch.allclose(got, ref, atol=3e-2, rtol=1e-2), float((got - ref).abs().max())
+    # vs the un-folded fp32 computation: the A operand is bf16(x) with a 40x outlier channel (error ~ 2^-9 * 60 * |w| per product)
+    assert float((got - full).abs().mean()) <= 2e-2 and float((got - full).abs().max()) <= 0.35, (float((got - full).abs().mean()), float((got - full).abs().max()))
+    assert torch.all(out[M:].float() == 7.0), "rows beyond M were written"
+
+
+@pytest.mark.parametrize("M", [500, 2560, 2311])
+def test_gemm_swiglu_ln_fold(gpu, M):
+    from cryovit_amd._lib import EPI_SWIGLU
+    from cryovit_amd.engine import ops
+
+    K, Hd = 128, 344
+    Hp = ops.round_up(Hd, 64)
+    x = rnd(M, K, seed=331, scale=1.5) - 0.2
+    w12, b12 = rnd(2 * Hd, K, seed=332, scale=K**-0.5), rnd(2 * Hd, seed=333)
+    gamma, beta = torch.exp(rnd(K, seed=334) * 0.5), rnd(K, seed=335, scale=0.2)
+    aw, bw, ab, bb = torch.zeros(Hp, K), torch.zeros(Hp, K), torch.zeros(Hp), torch.zeros(Hp)
+    aw[:Hd], bw[:Hd], ab[:Hd], bb[:Hd] = w12[:Hd], w12[Hd:], b12[:Hd], b12[Hd:]
+    iw = torch.stack([aw.reshape(-1, 8, K), bw.reshape(-1, 8, K)], 1).reshape(2 * Hp, K)
+    ib = torch.stack([ab.reshape(-1, 8), bb.reshape(-1, 8)], 1).reshape(2 * Hp)
+    R = ops.alloc_rows(M)
+    xd = torch.zeros(R, K, device=gpu)
+    xd[:M] = x.to(gpu)
+    xh, xl, rs = torch.zeros(R, K, dtype=torch.bfloat16, device=gpu), torch.zeros(R, K, dtype=torch.bfloat16, device=gpu), torch.zeros(R, 2, device=gpu)
+    ops.split_stream(xd, xh, xl, rs, rows=M, Cdim=K, eps=1e-6)
+    wq, bc = _ln_fold_pack(iw, ib, gamma, beta, 2 * Hp, gpu)
+    out = torch.zeros(R, Hp, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_SWIGLU, xh, wq, out, bc, m=M, n=2 * Hp, ln_rowstat=rs)
+    h = _ln_ref(x, w12, b12, gamma, beta, rs, M)
+    ref = F.silu(h[:, :Hd]) * h[:, Hd:]
+    got = out[:M].float().cpu()
+    assert torch.allclose(got[:, :Hd], ref, atol=2e-2, rtol=1e-2), float((got[:, :Hd] - ref).abs().max())
+    assert torch.all(got[:, Hd:] == 0)
+
+
+@pytest.mark.parametrize("b,heads,nt,K", [(3, 2, 29, 128), (4, 4, 1029, 256), (5, 4, 1029, 256)])
+def test_gemm_vt_ln_fold(gpu, b, heads, nt, K):
+    """V^T epilogue (MREG orientation) with the fold: small tiles, the persistent tile alone (4 x 1032 rows = 16 M tiles + a ragged
+    one) and the main + tail split."""
+    from cryovit_amd._lib import EPI_VT
+    from cryovit_amd.engine import ops
+
+    ntp, kp, C = ops.round_up(nt, 8), ops.round_up(nt, 64), heads * 64
+    M = b * ntp
+    x = rnd(M, K, seed=341, scale=1.5) + 0.4
+    w, bias = rnd(C, K, seed=342, scale=K**-0.5), rnd(C, seed=343)
+    gamma, beta = torch.exp(rnd(K, seed=344) * 0.5), rnd(K, seed=345, scale=0.2)
+    R = ops.alloc_rows(M)
+    xd = torch.zeros(R, K, device=gpu)
+    xd[:M] = x.to(gpu)
+    xh, xl, rs = torch.zeros(R, K, dtype=torch.bfloat16, device=gpu), torch.zeros(R, K, dtype=torch.bfloat16, device=gpu), torch.zeros(R, 2, device=gpu)
+    ops.split_stream(xd, xh, xl, rs, rows=M, Cdim=K, eps=1e-6)
+    wq, bc = _ln_fold_pack(w, bias, gamma, beta, ops.round_up(C, 128), gpu)
+    vt = torch.zeros(b, heads, 64, kp, dtype=torch.bfloat16, device=gpu)
+    ops.gemm(EPI_VT, xh, wq, vt, bc, m=M, n=C, heads=heads, ntp=ntp, kp=kp, ldc=0, ln_rowstat=rs)
+    v = _ln_ref(x, w, bias, gamma, beta, rs, M).reshape(b, ntp, heads, 64).permute(0, 2, 3, 1)
+    got = vt.float().cpu()
+    assert torch.allclose(got[..., :ntp], v, atol=2e-2, rtol=1e-2), float((got[..., :ntp] - v).abs().max())
+    assert torch.all(got[..., ntp:] == 0)
+
+
+def test_final_norm_hl_equals_fp32_form(gpu):
+    """cvx_final_norm_features_hl on (hi, lo) == cvx_final_norm_features on the fp32 array hi + lo, bit for bit, all three outputs."""
+    from cryovit_amd.engine import ops
+
+    slices, hp, wp, C, n_reg = 3, 5, 7, 384, 4
+    npatch, tok0 = hp * wp, 1 + n_reg
+    ntp = ops.round_up(npatch + tok0, 8)
+    R = ops.alloc_rows(slices * ntp)
+    x = rnd(R, C, seed=351, scale=4.0) + 1.0
+    hi, lo = _split(x)
+    xs = (hi.float() + lo.float()).to(gpu)
+    w, b = (rnd(C, seed=352) * 0.1 + 1).to(gpu), rnd(C, seed=353).to(gpu)
+    outs = []
+    for form in (0, 1):
+        f16 = torch.zeros(C, slices, hp, wp, dtype=torch.float16, device=gpu)
+        cl = torch.zeros(slices * npatch, C, dtype=torch.float16, device=gpu)
+        tk = torch.zeros(slices, npatch, C, device=gpu)
+        kw = dict(slices=slices, ntp=ntp, tok0=tok0, hp=hp, wp=wp, Cdim=C, feats_f16=f16, d_total=slices, d0=0, feats_cl=cl, tokens_f32=tk)
+        if form:
+            ops.final_norm_features_hl(hi.to(gpu), lo.to(gpu), w, b, 1e-6, **kw)
+        else:
+            ops.final_norm_features(xs, w, b, 1e-6, **kw)
+        outs.append((f16, cl, tk))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    ref = F.layer_norm(xs.cpu().reshape(-1, C)[: slices * ntp].reshape(slices, ntp, C)[:, tok0 : tok0 + npatch], (C,), w.cpu(), b.cpu(), 1e-6)
+    assert torch.allclose(outs[1][2].cpu(), ref, atol=1e-4, rtol=1e-4)
