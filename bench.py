@@ -153,7 +153,7 @@ def stage_breakdown(vit, head, vol, labels, feats_cl, feats_f16, sb: int) -> dic
     def gemm_label(epi, a, w, *_, **k):
         if epi in names:
             return names[epi]
-        if epi == _lib.EPI_RESID:
+        if epi in (_lib.EPI_RESID, _lib.EPI_RESID_HL):
             return "gemm_proj" if w.shape[1] == vit.cfg.dim else "gemm_w3"
         return "gemm_qk"
 
@@ -165,6 +165,9 @@ def stage_breakdown(vit, head, vol, labels, feats_cl, feats_f16, sb: int) -> dic
         wrap("preprocess_patches", lambda *a, **k: "preprocess")
         wrap("init_tokens", lambda *a, **k: "init_tokens")
         wrap("final_norm_features", lambda *a, **k: "final_norm_features")
+        wrap("final_norm_features_hl", lambda *a, **k: "final_norm_features")
+        wrap("split_stream", lambda *a, **k: "split_stream")
+        wrap("rowstat_finalize", lambda *a, **k: "layernorm")  # what is left of the 80 LayerNorm passes: 79 row-constant launches
         torch.cuda.synchronize()
         ev("_start")
         for d0 in range(0, D_, sb):

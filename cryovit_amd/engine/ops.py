@@ -79,8 +79,8 @@ def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bia
     dev = _dev_check(a, w, out, bias, gamma, pos, ln_rowstat, out2, stat_part)
     assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and bias.dtype == torch.float32
     assert a.stride(-1) == 1 and w.is_contiguous() and bias.numel() >= w.shape[0] * (2 if ln_rowstat is not None else 1)
-    if ln_rowstat is not None and (ln_rowstat.dtype != torch.float32 or ln_rowstat.numel() < 2 * m):
-        raise _lib.CvxError("gemm: ln_rowstat must be fp32 with >= 2*m elements")
+    if ln_rowstat is not None and (ln_rowstat.dtype != torch.float32 or ln_rowstat.numel() < 2 * round_up(m, ROW_PAD)):
+        raise _lib.CvxError("gemm: ln_rowstat must be fp32 [rows, 2] with rows >= m rounded up to 256 (whole tiles are fetched)")
     if epilogue == _lib.EPI_RESID_HL:
         if out2 is None or stat_part is None or out.dtype != torch.bfloat16 or out2.dtype != torch.bfloat16 or stat_part.dim() != 3:
             raise _lib.CvxError("gemm: EPI_RESID_HL needs bf16 out / out2 and stat_part fp32 [n_pad/64, rows, 2]")
