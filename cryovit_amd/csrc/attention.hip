@@ -76,7 +76,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     // as long as the row maxima of the tile stay within DEFER (log2 units) of the value subtracted.  The VALU, not the
     // matrix pipe, bounds this kernel at head_dim 64 (PMC: VALU active 73 % of SIMD cycles, MFMA 39 %); the 32 fused
     // multiply-adds per tile this removes were 15 % of its vector instructions, for 2 more MFMAs on the idle pipe.
-    constexpr bool AUG = VARIANT == 6;
+    constexpr bool AUG = VARIANT == 6 || VARIANT == 7;
+    constexpr bool PSUM_TRIGGER = VARIANT == 7;  // the maximum is only looked at in tile 0; later tiles watch their probability sums
     constexpr float DEFER = 3.0f;  // p <= 2^3 before a row's maximum is raised (bf16 P is floating point: same relative precision)
     bf16x8 kaug, qaug;
     [[maybe_unused]] float m_used = 0.f;  // what is currently subtracted (exactly representable in bf16)
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     // A query block whose rows all belong to wave 0 (1029 tokens = 8 x 128 + 5: every ninth block) runs as ONE wave: waves 1-3
     // leave at once (a hardware barrier only counts the waves still alive) and wave 0 issues their DMA pieces too -- their wave
     // slots go back to the CU instead of idling through 17 tiles of barriers.
-    const bool lone = VARIANT == 6 && qb * 128 + 32 >= ntok;  // (uniform per workgroup)
+    const bool lone = AUG && qb * 128 + 32 >= ntok;  // (uniform per workgroup)
     if (lone && wave != 0) return;
     auto issue = [&](int j, int buf) {
         const uint32_t kt = lds_addr(smem) + buf * 2 * ATT_TILE_BYTES + wave * 1024;
@@ -142,7 +143,10 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     // Q has landed (and tile 0 / 1 with it: the loop's own first wait is then a no-op); "+v" pins every use of qf below this
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
     int buf = 0;  // buffer of tile j
+    const char* kt = smem;
+    [[maybe_unused]] bool redo = false;  // VARIANT 7: tile j is computed again, with the row maxima (no new wait / barrier / DMA)
     for (int j = 0; j < nkv; ++j) {
+        if (!PSUM_TRIGGER || !redo) {
         if (!ABL_NOSYNC || j == 0) {
             // tile j landed (with three buffers tile j+1 may stay in flight); every wave is done with tile j-1
             if (NBUF == 3 && j + 1 < nkv) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -154,8 +158,11 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
         } else if (!ABL_NODMA && j + 1 < nkv) {
             issue(ABL_NOSYNC ? 0 : j + 1, ABL_NOSYNC ? 1 : (buf ^ 1));
         }
-        const char* kt = smem + (ABL_NOSYNC || ABL_NODMA ? 0 : buf) * 2 * ATT_TILE_BYTES;
+        kt = smem + (ABL_NOSYNC || ABL_NODMA ? 0 : buf) * 2 * ATT_TILE_BYTES;
         buf = NBUF == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
+        }
+        [[maybe_unused]] const bool anchor = j == 0 || redo;
+        redo = false;
         const char* vtile = kt + ATT_TILE_BYTES;
         // 1029 tokens = 8 x 128 + 5: in the last query block only wave 0 owns real rows.  The other three keep feeding the
         // LDS-DMA and the barriers (the tile is a workgroup effort) but skip the products and the softmax -- their issue
@@ -164,31 +171,81 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
 
         // ---- S^T[t] = K_t Q^T : rows = keys (registers), col = query (lane) ----
         f32x16 s[2];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if constexpr (AUG) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kaug, qaug, s[t], 0, 0, 0);  // -m_used for every key
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kt + t * 4096 + koff + (((2 * ks + h) ^ ksw) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
-            }
-        }
-
-        // ---- mask keys >= ntok (last tile only; wave-uniform test) ----
         const int kv0 = j * KV_TILE;
-        if (kv0 + KV_TILE > ntok) {
+        auto compute_s = [&]() {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if constexpr (AUG) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kaug, qaug, s[t], 0, 0, 0);  // -m_used for every key
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(kt + t * 4096 + koff + (((2 * ks + h) ^ ksw) << 4));
+                    s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+                }
+            }
+            // ---- mask keys >= ntok (last tile only; wave-uniform test) ----
+            if (kv0 + KV_TILE > ntok) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (kv0 + 32 * t + pi_row(rho) >= ntok) s[t][i] = -INFINITY;
+                    }
+            }
+        };
+        if constexpr (!PSUM_TRIGGER) compute_s();
+
+        if constexpr (PSUM_TRIGGER) {
+            // ---- online softmax on S' = S - m_used (log2 units), VARIANT 7 ----
+            // Tile 0 anchors every row at its own maximum (16 v_max3 + one cross-half exchange, once per query block).  After that the
+            // row maximum is not computed on the common path: p = exp2(S') is floating point, so a row whose later scores exceed its
+            // anchor simply produces p > 1 -- the same relative precision in bf16 P, in the fp32 sums and in O.  What has to be
+            // prevented is overflow, and for that the probability SUM the tile computes anyway is enough: when a lane's sum passes
+            // 2^24 the whole tile is computed AGAIN (same LDS tile: no wait, barrier or DMA) in the anchored form.  Per 64-key tile
+            // this removes 16 v_max3, the exchange and the compare chain from a loop whose vector ISSUE slots, not its matrix pipe,
+            // set the pace.
+            float psum;
+            compute_s();
+            if (anchor) {
+                // tile 0, or a tile whose probability sums ran away: the rows are (re-)anchored at their maximum exactly as variant 6
+                // does in every tile.  Tile 0 takes the maximum whatever its sign (a row whose scores are all far below zero must not
+                // underflow to l = 0); later the anchor only ever goes up.  The anchor is bf16-representable so that the products of
+                // the next tiles subtract exactly what the rescale here assumes.
+                float mloc = s[0][0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) mloc = fmaxf(mloc, s[0][i]);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mloc = fmaxf(mloc, s[1][i]);
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float m_new = (float)(__bf16)(m_used + (j == 0 ? mloc : fmaxf(mloc, 0.f)));
+                const float delta = m_new - m_used;
+                m_used = m_new;
+                if (h == 0) qaug[0] = (__bf16)(-m_new);
+                const float alpha = j == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);  // (tile 0: O = l = 0, and -delta may be huge)
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; s[0][i] -= delta; s[1][i] -= delta; }
+            }
+            psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int rho = (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (kv0 + 32 * t + pi_row(rho) >= ntok) s[t][i] = -INFINITY;
+                    const float p = __builtin_amdgcn_exp2f(s[t][i]);
+                    s[t][i] = p;
+                    psum += p;
                 }
-        }
-
-        if constexpr (AUG) {
+            // some row's probabilities outgrew its anchor by 2^19 or more (or overflowed): the tile is computed again, this time
+            // with the maximum (never twice: the anchored pass is final -- variant 6's own bound, p <= 2^(half a bf16 spacing of m))
+            if (!anchor && __builtin_amdgcn_ballot_w64(!(psum <= 16777216.0f)) != 0) {
+                redo = true;
+                --j;
+                continue;
+            }
+            l_run += psum;
+        } else if constexpr (AUG) {
             // ---- online softmax on S' = S - m_used (log2 units) ----
             float mloc = s[0][0];
 #pragma unroll
@@ -453,7 +510,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restr
 
 using namespace cvx;
 
-std::atomic<int> g_attn_variant{6};     // cvx_set_option("attn_variant"); 6 = maximum subtracted inside the product (default)
+std::atomic<int> g_attn_variant{7};     // cvx_set_option("attn_variant"); 7 = maximum subtracted inside the product, re-anchoring triggered by the probability sums (default); 6 = by the tile maxima
 std::atomic<int> g_attn_xcd_remap{1};   // cvx_set_option("attn_xcd_remap")
 
 extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
@@ -465,7 +522,7 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     // Variant 6's single-wave query blocks derive the departed waves' DMA offsets by XOR-ing 64 into wave 0's own, which is the other
     // waves' row term only while a K row's byte pitch is a multiple of 128 (ldqk % 64 == 0: every DINOv2 width).  Other leading
     // dimensions take the general kernel with the same arithmetic plan (variant 3).
-    if (variant == 6 && ldqk % 64 != 0) variant = 3;
+    if ((variant == 6 || variant == 7) && ldqk % 64 != 0) variant = 3;
     const int rows_per_block = variant == 4 ? 192 : variant == 5 ? 256 : 128;
     const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;
@@ -477,6 +534,7 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
         case 1: k = k_attention<1>; break;
         case 3: k = k_attention<3>; break;
         case 6: k = k_attention<6>; break;
+        case 7: k = k_attention<7>; break;
 #ifdef CVX_ABLATION  // timing-only, garbage output
         case 10: k = k_attention<10>; break;
         case 11: k = k_attention<11>; break;

@@ -223,15 +223,17 @@ def test_layernorm(gpu, C):
 def attn_variant(request):
     """All attention kernels kept in attention.hip are parity-tested: 0 = 32 query rows per wave (4-wave blocks),
     3 = three K/V buffers, 4 / 5 = 64 query rows per wave in 3- / 4-wave blocks, 6 (default) = 0 with the running maximum
-    subtracted inside the QK^T product (augmented k-step) and raised only when a row outgrows it by 2^3."""
+    subtracted inside the QK^T product (augmented k-step) and raised only when a row outgrows it by 2^3, 7 (default) = 6 with the
+    re-anchoring triggered by the tile's probability SUMS (the maximum is only computed in tile 0; a jump beyond the range of one
+    exp2 recomputes the tile against raised anchors)."""
     from cryovit_amd import _lib
 
     _lib.set_option("attn_variant", request.param)
     yield request.param
-    _lib.set_option("attn_variant", 6)  # the default
+    _lib.set_option("attn_variant", 7)  # the default
 
 
-@pytest.mark.parametrize("attn_variant", [0, 3, 4, 5, 6], indirect=True)
+@pytest.mark.parametrize("attn_variant", [0, 3, 4, 5, 6, 7], indirect=True)
 @pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1)])
 def test_attention(gpu, nt, slices, heads, attn_variant):
     from cryovit_amd.engine import ops
@@ -285,11 +287,13 @@ def test_attention_odd_leading_dimension(gpu, pad):
     assert torch.allclose(got[:, :nt], ref, atol=2e-2, rtol=2e-2), float((got[:, :nt] - ref).abs().max())
 
 
-@pytest.mark.parametrize("spike", [4.0, 60.0, -60.0])
-@pytest.mark.parametrize("attn_variant", [0, 4, 6], indirect=True)
+@pytest.mark.parametrize("spike", [4.0, 9.0, 60.0, -60.0])
+@pytest.mark.parametrize("attn_variant", [0, 4, 6, 7], indirect=True)
 def test_attention_forced_rescale(gpu, attn_variant, spike):
     """One key row spiked against one query so the running max jumps in a late tile (rare-branch test).  spike 60: the jump
-    is far above the deferred-maximum threshold of variant 6 (its raise-and-rescale branch); spike -60 with the shift below:
+    is far above the deferred-maximum threshold of variant 6 (its raise-and-rescale branch) and beyond what one exp2 can hold
+    (variant 7: the tile is recomputed against raised anchors, several times); spike 9: a jump of ~2^100, variant 7's in-place
+    rescale from the probabilities; spike -60 with the shift below:
     every score of the tomogram is far below zero (rows must be anchored at their own maximum, not at 0)."""
     from cryovit_amd.engine import ops
 
