@@ -289,8 +289,9 @@ def cpu_baseline() -> dict:
 
 
 def measured_traffic() -> dict:
-    """PMC traffic of the dominant kernel, per launch, from the committed rocprofv3 --pmc passes of this round (collected
-    with tools/profile_dominant.sh; `rocprofv3` cannot run inside this process)."""
+    """PMC traffic of the dominant kernel, per launch, from the committed rocprofv3 --pmc passes (collected on the GPU box with
+    tools/profile_round.sh, condensed by tools/summarize_profiles.py; `rocprofv3` cannot run inside this process).  The JSON names
+    the commit it was measured at: a number from an older kernel is labelled as such, not passed off as this build's."""
     if not TRAFFIC_FILE.exists():
         return {"traffic": None}
     t = json.loads(TRAFFIC_FILE.read_text())
@@ -300,6 +301,7 @@ def measured_traffic() -> dict:
         "algorithmic_bytes": t["algorithmic_bytes_per_launch"],
         "traffic_source": f"profiles/{TRAFFIC_FILE.name} (rocprofv3 --pmc, separate passes; FETCH_SIZE x2 per the gfx950 correction: a "
                           "fabric-side counter that INCLUDES Infinity-Cache hits, i.e. an upper bound on HBM bytes)",
+        "traffic_measured_at_commit": t.get("measured_at_commit", "round 2 (before the LayerNorm fold)"), "traffic_kernel": t.get("kernel"),
     }
 
 
@@ -497,7 +499,7 @@ def main() -> None:
             "tflops_end_to_end": flops_tomo * world * args.steps / elapsed_max / 1e12,
             "frac_of_mfma_peak_end_to_end": flops_tomo * args.steps / elapsed_max / 1e12 / PEAK_BF16_TFLOPS,
             "dice": 2 * i / (sy + sp + 1e-3), "pred_fg_fraction": fg,
-            "roofline": {"bound": "mfma", "kernel": "k_gemm256 w12 GEMM 1536->8192 + fused SiLU gate (EpiSwiGLU)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "k_gemm256p_nreg<EpiSwiGLUT<LN>, FULL>: w12 GEMM 1536->8192, LayerNorm folded into the epilogue + fused SiLU gate", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, **measured_traffic(),
                          "launches_timed": n_launch, "avg_launch_ms": k_ms, "flops_per_launch": k_flops},
         }

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     }
 }
 
+#ifdef CVX_ABLATION
 // ---------------------------------------------------------------------------------------------------------------
 // 64 query rows per wave (two 32-row groups that share every K / V^T fragment read, the LDS-DMA and the barrier of a
 // tile): half the LDS reads, DMA instructions and barriers per query row, and inside ONE wave the softmax VALU work of
@@ -506,6 +507,8 @@ __global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restr
     }
 }
 
+#endif  // CVX_ABLATION
+
 }  // namespace cvx
 
 using namespace cvx;
@@ -521,8 +524,8 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     int variant = g_attn_variant;  // one read per call: a concurrent cvx_set_option cannot give a mixed launch
     // Variant 6's single-wave query blocks derive the departed waves' DMA offsets by XOR-ing 64 into wave 0's own, which is the other
     // waves' row term only while a K row's byte pitch is a multiple of 128 (ldqk % 64 == 0: every DINOv2 width).  Other leading
-    // dimensions take the general kernel with the same arithmetic plan (variant 3).
-    if ((variant == 6 || variant == 7) && ldqk % 64 != 0) variant = 3;
+    // dimensions take the general kernel (variant 0: a running maximum per tile).
+    if ((variant == 6 || variant == 7) && ldqk % 64 != 0) variant = 0;
     const int rows_per_block = variant == 4 ? 192 : variant == 5 ? 256 : 128;
     const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;
@@ -531,11 +534,11 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     dim3 grid((unsigned)nblk);
     void (*k)(const uint16_t*, long, const uint16_t*, uint16_t*, long, int, int, int, int, int, int, int);
     switch (variant) {
+        case 7: k = k_attention<7>; break;
+#ifdef CVX_ABLATION  // earlier schedules (parity-tested on the ablation build) and timing-only ones with garbage output
         case 1: k = k_attention<1>; break;
         case 3: k = k_attention<3>; break;
         case 6: k = k_attention<6>; break;
-        case 7: k = k_attention<7>; break;
-#ifdef CVX_ABLATION  // timing-only, garbage output
         case 10: k = k_attention<10>; break;
         case 11: k = k_attention<11>; break;
         case 12: k = k_attention<12>; break;
@@ -543,12 +546,14 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
 #endif
         default: k = k_attention<0>; break;
     }
+#ifdef CVX_ABLATION
     if (variant == 4 || variant == 5) {
         auto k64 = variant == 4 ? k_attention64<3> : k_attention64<4>;
         hipLaunchKernelGGL(k64, grid, dim3(rows_per_block), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo,
                            heads, ntok, ntp, kp, heads * 64, nqb, xcd_remap);
         return cvx_check_launch();
     }
+#endif
     hipLaunchKernelGGL(k, grid, dim3(ATT_THREADS), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo, heads,
                        ntok, ntp, kp, heads * 64, nqb, xcd_remap);
     return cvx_check_launch();

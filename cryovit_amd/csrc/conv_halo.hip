@@ -29,6 +29,7 @@ struct HaloCfg {
     static constexpr int LDS_BYTES = HALO_BYTES + W_BYTES;
 };
 
+#ifdef CVX_ABLATION  // k_conv3_halo: the round-1 per-tile form (A/B runs only; the product runs k_conv3_march)
 template <int CIN, int ACT>
 __global__ __launch_bounds__(256) void k_conv3_halo(const uint16_t* __restrict__ in, const uint16_t* __restrict__ wt /*[16][ldw]*/,
                                                     long ldw, const float* __restrict__ bias, uint16_t* __restrict__ out, int cout,
@@ -137,6 +138,7 @@ static int launch_halo(const cvx_conv3d_desc& d, hipStream_t st) {
                        (uint16_t*)d.out, d.cout, d.D, d.H, d.W, d.dil, tiles_x, tiles_y, ntiles);
     return cvx_check_launch();
 }
+#endif  // CVX_ABLATION
 
 // ---------------------------------------------------------------------------------------------------
 // Z-MARCHING form (round 2).  The tile kernel above stages all three planes of every tile from scratch, synchronously: a
@@ -378,6 +380,7 @@ int conv3_march_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
 }
 
 // used by cvx_conv3d_f16 (gemm.hip) for the shapes this kernel is built for
+#ifdef CVX_ABLATION  // the round-1 per-tile halo kernel: superseded by the z-marching ring, kept for A/B runs
 bool conv3_halo_eligible(const cvx_conv3d_desc& d) {
     return d.n_pad == 16 && d.cout % 4 == 0 && d.cout <= 16 && (d.C == 8 || d.C == 16 || d.C == 32) && d.k_pad >= 27 * d.C;
 }
@@ -388,5 +391,6 @@ int conv3_halo_dispatch(const cvx_conv3d_desc& d, hipStream_t st) {
         default: return launch_halo<32>(d, st);
     }
 }
+#endif  // CVX_ABLATION
 
 }  // namespace cvx

@@ -2,7 +2,9 @@
 #include "gemm_core.h"
 #include "gemm256.h"
 #include "gemm256p.h"
-#include "gemm4w.h"
+#ifdef CVX_ABLATION
+#include "gemm4w.h"  // the 4-wave tile: measured 3 % slower, kept for A/B runs only
+#endif
 #include "../../include/cryovit_hip.h"
 #include "host_util.h"
 #include <atomic>
@@ -542,6 +544,7 @@ template <class Epi> static constexpr int epilogue_cycles() { return 12000; }   
 template <> constexpr int epilogue_cycles<EpiResid>() { return 40000; }              // fp32 read-modify-write
 template <> constexpr int epilogue_cycles<EpiF32>() { return 20000; }
 
+#ifdef CVX_ABLATION
 template <class Epi, bool MREG, int VARIANT>
 __global__ __launch_bounds__(G4W_THREADS) void k_gemm4w(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, int nks,
                                                          int tiles_n, int tiles_m, Epi epi) {
@@ -555,6 +558,7 @@ __global__ __launch_bounds__(G4W_THREADS) void k_gemm4w(const uint16_t* A, long 
         gemm4w_body<VARIANT>(Wt, ldw, A, lda, nks, (long)tr * 256, (long)tl * 256, epi, smem);
     }
 }
+#endif
 
 static bool use_gemm256(long M, long Npad, long Kpad) {
     return g_use_gemm256 && Npad % 256 == 0 && Kpad % BK == 0 && Kpad / BK >= 4 && M >= 1024;
@@ -564,6 +568,7 @@ template <class Epi, bool MREG>
 static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw, long M, long Npad, long Kpad, const Epi& epi,
                       hipStream_t st) {
     const int tiles_n = (int)(Npad / 256), tiles_m = (int)((M + 255) / 256);
+#ifdef CVX_ABLATION
     if (g_use_gemm256 == 2) {  // one-wave-per-SIMD tile (gemm4w.h)
         auto k4 = g_gemm256_variant == 1 ? k_gemm4w<Epi, MREG, 1> : g_gemm256_variant == 2 ? k_gemm4w<Epi, MREG, 2> : k_gemm4w<Epi, MREG, 0>;
         CVX_HIP(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, G4W_LDS_BYTES));
@@ -571,16 +576,21 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
                            tiles_n, tiles_m, epi);
         return cvx_check_launch();
     }
+#endif
     const int variant = g_gemm256_variant;
     if constexpr ((!MREG && (epi_has_preload<Epi>::value || epi_has_produce<Epi>::value || epi_has_hl<Epi>::value)) || (MREG && epi_is_mreg<Epi>::value)) {
         if (variant == 9 || variant == 29) {
             // one workgroup per CU (128 KiB of LDS each), a multiple of 8 so every XCD gets the same number
-            static int n_cu = 0;
+            // (per DEVICE: a process may drive several GPUs, one volume per stream each)
+            static std::atomic<int> n_cu_of[64];
+            int dev = 0;
+            CVX_HIP(hipGetDevice(&dev));
+            int n_cu = dev >= 0 && dev < 64 ? n_cu_of[dev].load() : 0;
             if (!n_cu) {
-                int dev = 0, n = 0;
-                CVX_HIP(hipGetDevice(&dev));
+                int n = 0;
                 CVX_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
                 n_cu = n >= 8 ? n / 8 * 8 : 8;
+                if (dev >= 0 && dev < 64) n_cu_of[dev] = n_cu;
             }
             const int ntiles = tiles_n * tiles_m;
             const int grid = ntiles >= n_cu ? n_cu : (ntiles + 7) / 8 * 8;
@@ -606,12 +616,12 @@ static int launch_256(const uint16_t* A, long lda, const uint16_t* Wt, long ldw,
         k = k_gemm256_mreg<Epi, 0>;
     } else {
         switch (variant) {
+#ifdef CVX_ABLATION  // the measured-and-rejected schedules and the timing-only builds (stamps / garbage-output ablations): never in the product library
             case 1: k = k_gemm256_nreg<Epi, 1>; break;
             case 5: k = k_gemm256_nreg<Epi, 5>; break;
             case 6: k = k_gemm256_nreg<Epi, 6>; break;
             case 7: k = k_gemm256_nreg<Epi, 7>; break;
             case 8: k = k_gemm256_nreg<Epi, 8>; break;
-#ifdef CVX_ABLATION  // timing-only builds (stamps / garbage-output ablations): never in the product library
             case 20: k = k_gemm256_nreg<Epi, 20>; break;
             case 21: k = k_gemm256_nreg<Epi, 21>; break;
             case 10: k = k_gemm256_nreg<Epi, 10>; break;
@@ -766,10 +776,10 @@ extern "C" int cvx_set_option(const char* name, int value) {
     const bool abl = false;
 #endif
     if (!strcmp(name, "use_gemm256")) {
-        if (!one_of({0, 1, 2})) return cvx_fail("set_option: use_gemm256 must be 0, 1 or 2");
+        if (!one_of({0, 1}) && !(abl && value == 2)) return cvx_fail("set_option: use_gemm256 must be 0 or 1 (2, the 4-wave tile, needs a -DCVX_ABLATION build)");
         g_use_gemm256 = value;
     } else if (!strcmp(name, "gemm256_variant")) {
-        if (!one_of({0, 1, 2, 5, 6, 7, 8, 9}) && !(abl && one_of({10, 11, 12, 13, 20, 21, 29})))
+        if (!one_of({0, 9}) && !(abl && one_of({1, 2, 5, 6, 7, 8, 10, 11, 12, 13, 20, 21, 29})))
             return cvx_fail("set_option: unknown gemm256_variant (ablation variants need a -DCVX_ABLATION build)");
         g_gemm256_variant = value;
     } else if (!strcmp(name, "gemm_stagger")) {
@@ -787,7 +797,8 @@ extern "C" int cvx_set_option(const char* name, int value) {
         g_resid_stagger = value;
     }
     else if (!strcmp(name, "conv_halo")) {
-        if (!one_of({0, 1, 2})) return cvx_fail("set_option: conv_halo is 0 (implicit GEMM), 1 (tile halo) or 2 (z-marching ring)");
+        if (!one_of({0, 2}) && !(abl && value == 1))
+            return cvx_fail("set_option: conv_halo is 0 (implicit GEMM) or 2 (z-marching ring); 1 (the round-1 tile-halo kernel) needs a -DCVX_ABLATION build");
         g_conv_halo = value;
     }
     else if (!strcmp(name, "conv_wide")) g_conv_wide = value != 0;
@@ -798,7 +809,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
         g_ln_policy = value;
     }
     else if (!strcmp(name, "attn_variant")) {
-        if (!one_of({0, 1, 3, 4, 5, 6, 7}) && !(abl && one_of({10, 11, 12, 13})))
+        if (!one_of({0, 7}) && !(abl && one_of({1, 3, 4, 5, 6, 10, 11, 12, 13})))
             return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");
         g_attn_variant = value;
     } else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value != 0;
@@ -1023,6 +1034,8 @@ extern "C" int cvx_conv3d_f16(const cvx_conv3d_desc* d, hipStream_t st) {
     if (d->cout % 4) return cvx_fail("conv3d: C_out must be a multiple of 4");
     const int halo = g_conv_halo;
     if (halo == 2 && conv3_march_eligible(*d)) return conv3_march_dispatch(*d, st);
+#ifdef CVX_ABLATION
     if (halo && conv3_halo_eligible(*d)) return conv3_halo_dispatch(*d, st);
+#endif
     return d->act ? conv3_dispatch<1>(*d, st) : conv3_dispatch<0>(*d, st);
 }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_conv3_out(const uint16_t* __restrict__ 
         if (labels) {
             const int lab = labels[v];
             if (lab > -1) {                                          // base_model.py:99
-                const float ph = p < 0.5f ? 0.f : 1.f;               // metrics.py:38
+                const float ph = p < mask_thr ? 0.f : 1.f;           // metrics.py:38 (DiceMetric.thresh: the SAME threshold as the mask)
                 inter += (float)lab * ph; ysum += (float)lab; psum += ph;
             }
         }

@@ -163,8 +163,16 @@ class HeadEngine:
             self._ws[key] = torch.zeros(ops.alloc_rows(rows) * ch + 4096, dtype=torch.float16, device=self.device)
         return self._ws[key]
 
+    @staticmethod
+    def _threshold(mask_threshold, dice_threshold) -> float:
+        """The fused output kernel compares against ONE threshold: DiceMetric's (metrics.py:38) and the uint8 mask's (callbacks.py:100)."""
+        if mask_threshold is not None and dice_threshold is not None and float(mask_threshold) != float(dice_threshold):
+            raise ops._lib.CvxError("head: the mask threshold and the Dice threshold of one call must agree (one fused comparison)")
+        t = mask_threshold if mask_threshold is not None else dice_threshold
+        return 0.5 if t is None else float(t)
+
     def forward(self, feats_cl: torch.Tensor, D: int, h: int, w_: int, labels=None, want_logits=False, want_probs=True,
-                mask_threshold: float | None = None):
+                mask_threshold: float | None = None, dice_threshold: float | None = None):
         """feats_cl: fp16 channels-last features [D*h*w (+slack rows), C_in].  Returns dict with
         ``probs`` / ``logits`` fp32 [D, 16h, 16w], ``dice_sums`` (fp32[3] device tensor) when labels are given and
         ``mask`` uint8 [D, 16h, 16w] = (probs >= mask_threshold) when a threshold is given.  ONE C call: cvx_head_forward."""
@@ -184,7 +192,7 @@ class HeadEngine:
             raise ops._lib.CvxError(f"head: labels must be int8 {shape}")
         ops.call(dev, "cvx_head_forward", ops._lib.load().cvx_head_forward, C.byref(self._desc), C.byref(self._make_ws(D, h, w_)),
                  feats_cl.data_ptr(), D, h, w_, ops._p(logits), ops._p(probs), ops._p(labels), ops._p(dice), ops._p(mask),
-                 0.5 if mask_threshold is None else float(mask_threshold))
+                 self._threshold(mask_threshold, dice_threshold))
         return {"logits": logits, "probs": probs, "dice_sums": dice, "mask": mask}
 
     def _forward_py(self, feats_cl: torch.Tensor, D: int, h: int, w_: int, labels=None, want_logits=False, want_probs=True,

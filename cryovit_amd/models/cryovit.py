@@ -114,7 +114,9 @@ class CryoVIT(EvalProtocol, nn.Module):
     def predict_with_dice(self, feats_cl: Tensor, D: int, h: int, w: int, labels: Tensor | None):
         """Fused inference used by the end-to-end runner: channels-last fp16 features straight from the encoder ->
         probabilities and (with labels) the masked Dice of ``_masked_predict`` + ``DiceMetric``."""
-        out = self.engine().forward(feats_cl, D, h, w, labels=None if labels is None else labels.to(self._device, torch.int8).contiguous())
+        thr = next((m.thresh for m in getattr(self, "metric_fns", {}).values() if hasattr(m, "thresh")), None)  # DiceMetric(threshold)
+        out = self.engine().forward(feats_cl, D, h, w, labels=None if labels is None else labels.to(self._device, torch.int8).contiguous(),
+                                    dice_threshold=thr)
         dice = None
         if labels is not None:
             i, sy, sp = out["dice_sums"].cpu().tolist()

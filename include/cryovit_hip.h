@@ -205,7 +205,8 @@ int cvx_groupnorm_act_f16(const void* x, const float* w, const float* b, void* o
 /* Last layer of the head at full resolution, channels-last fp16 in[D][H][W][8]:
  *   conv3x3x3(8->1, w fp32 [27][8] tap-major) + bias, clip(+-5) -> logits fp32 (nullable), sigmoid -> probs fp32
  *   (nullable), and masked Dice partial sums (labels int8 nullable; dice must be zeroed by the caller):
- *   dice[0] += sum(y*p_hat), dice[1] += sum(y), dice[2] += sum(p_hat) over labels > -1, p_hat = (p >= 0.5).
+ *   dice[0] += sum(y*p_hat), dice[1] += sum(y), dice[2] += sum(p_hat) over labels > -1, p_hat = (p >= mask_threshold): the
+ *   threshold of DiceMetric (configs/model/metrics/dice_metric.yaml: 0.5) and of the uint8 mask are ONE parameter.
  * Replaces output_layer.2 + clip + sigmoid (cryovit.py:33,39,49) and the reductions of
  * base_model.py:99-110 / metrics.py:36-41.  (output_layer.0 + GELU runs through cvx_conv3d_f16.)
  * scratch: >= 3*CVX_DICE_BLOCKS floats (per-block partial sums, reduced in a fixed order: reproducible).

@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = ROOT / "gpurun_out" / f"prof_{tag}"
 dst = ROOT / "profiles"
-DOM = "k_gemm256p_nreg<cvx::EpiSwiGLU"
+DOM = "k_gemm256p_nreg<cvx::EpiSwiGLU"  # (EpiSwiGLUT<true>: the LN-folded form the ViT path launches)
 
 stats = glob.glob(str(src / "stats" / "**" / "*kernel_stats.csv"), recursive=True)
 if stats:
@@ -48,7 +48,7 @@ if arows:
         w.writeheader()
         w.writerows(arows)
     am = {k: sum(v[1:]) / max(1, len(v) - 1) for k, v in avals.items()}
-    a = {"kernel": "k_attention<0> (default variant), 128 slices x 24 heads x 1029 tokens, head_dim 64", "per_launch_means": am}
+    a = {"kernel": "k_attention (default variant: cvx_set_option attn_variant), 128 slices x 24 heads x 1029 tokens, head_dim 64", "per_launch_means": am}
     if "SQ_INSTS_MFMA" in am and "SQ_INSTS_VALU" in am:
         a["valu_per_mfma"] = am["SQ_INSTS_VALU"] / am["SQ_INSTS_MFMA"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in am and "SQ_BUSY_CYCLES" in am:
@@ -77,11 +77,19 @@ if out_rows:
         w.writerows(out_rows)
     mean = lambda k: sum(vals[k][1:]) / max(1, len(vals[k]) - 1)  # noqa: E731  (the first launch is the cold one)
     M, K, N = 128 * 1032, 1536, 8192
-    alg = M * K * 2 + N * K * 2 + M * (N // 2) * 2
+    alg = M * K * 2 + N * K * 2 + M * (N // 2) * 2 + M * 8 + 2 * N * 4  # + row constants and b' / column sums of the fold
     fetch, write = mean("FETCH_SIZE") * 1024 * 2, mean("WRITE_SIZE") * 1024
     ms = sum(dur[1:]) / max(1, len(dur) - 1)
+    import subprocess
+
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    except OSError:
+        commit = ""
     d = {
-        "kernel": "k_gemm256p_nreg<EpiSwiGLU, FULL> (persistent 256x256x64 tile, gemm256p.h)",
+        "kernel": "k_gemm256p_nreg<EpiSwiGLUT<LN = true>, FULL> (persistent 256x256x64 tile, gemm256p.h; LayerNorm folded into the epilogue)",
+        "measured_at_commit": commit,  # HEAD of the tree whose gpurun_out/prof_<tag> was summarised (the kernel sources it was built from)
+        "tag": tag,
         "shape": f"M={M} (128 slices x 1032 padded tokens), K={K}, N={N} -> out bf16 [M,{N // 2}]",
         "collection": f"rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE | SQ_*), "
                       f"tools/run_one_gemm.py on the product library, mean of launches 2..6; rows: profiles/{tag}_pmc_dominant.csv",
