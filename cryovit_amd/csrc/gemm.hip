@@ -736,7 +736,7 @@ using namespace cvx;
 
 extern std::atomic<int> g_attn_variant, g_attn_xcd_remap;  // attention.hip
 extern std::atomic<int> g_ln_policy;                         // norm.hip
-extern std::atomic<int> g_win_attn_prefetch;                 // hiera.hip
+extern std::atomic<int> g_win_attn_prefetch, g_win_attn_x32; // hiera.hip
 
 extern "C" int cvx_debug_read_gemm256(unsigned long long* out32) {
     CVX_HIP(hipMemcpyFromSymbol(out32, HIP_SYMBOL(cvx::g_gemm256_dbg), sizeof(unsigned long long) * 32));
@@ -804,6 +804,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
     else if (!strcmp(name, "conv_wide")) g_conv_wide = value != 0;
     else if (!strcmp(name, "convt_small")) g_convt_small = value != 0;
     else if (!strcmp(name, "win_attn_prefetch")) g_win_attn_prefetch = value != 0;
+    else if (!strcmp(name, "win_attn_x32")) g_win_attn_x32 = value != 0;
     else if (!strcmp(name, "ln_policy")) {
         if (!one_of({0, 1, 2, 3})) return cvx_fail("set_option: ln_policy is a 2-bit mask (1: cacheable loads, 2: rows walked from the end)");
         g_ln_policy = value;

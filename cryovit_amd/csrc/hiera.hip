@@ -69,12 +69,21 @@ __global__ __launch_bounds__(256) void k_sam_patches(const void* __restrict__ sr
 // PF (256-thread blocks, head_dim % 8 == 0, power-of-two window, 16-B aligned rows): the K / V tile of the NEXT 64 keys is fetched into
 // registers while the current one is consumed and written to LDS after the barrier (16-B pieces, row / column of every piece
 // computed once) -- the plain form stages each tile synchronously with 8-B pieces and two divisions per piece.
-template <int DSTEPS, bool PF = false>
+// X32 (head_dim % 8 == 0): both products on v_mfma_f32_16x16x32_bf16, twice the rate of the 16x16x16 form on gfx950.  The k-slots
+// 8g .. 8g+7 of a lane are 4 + 4 values: for S^T the head dims 32s + 8g .. +7 (one 16-B read of a K row, head dim padded to a
+// multiple of 32 with zero columns); for O^T the keys 16j + 4g .. +3 and 16(j+1) + 4g .. +3 of TWO 16-key sub-tiles -- exactly the
+// two accumulator fragments (-> P^T) and the two transposed V reads the 16x16x16 form fed to two separate MFMAs.
+typedef short v8s __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 cat8(v4s a, v4s b) { return __builtin_bit_cast(bf16x8, v8s{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}); }
+
+template <int DSTEPS, bool PF = false, bool X32 = false>
 __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restrict__ q, long ldq, const uint16_t* __restrict__ k,
                                                        const uint16_t* __restrict__ v, long ldkv, uint16_t* __restrict__ out,
                                                        long ldo, int hd, int heads, int G, int ws, int Gq, int wsq,
                                                        float scale_log2e) {
-    constexpr int LDR = 16 * DSTEPS + 8;  // LDS row stride (elements): 16-lane row reads land on distinct bank pairs
+    constexpr int NQ = (DSTEPS + 1) / 2;                      // X32: 32-deep k-steps of the S^T product
+    constexpr int KW = X32 ? 32 * NQ : 16 * DSTEPS;           // staged row width (head dim padded with zero columns)
+    constexpr int LDR = KW + 8;  // LDS row stride (elements): 16-lane row reads land on distinct bank groups (8-B and 16-B reads)
     __shared__ __attribute__((aligned(16))) uint16_t Ks[64 * LDR];
     __shared__ __attribute__((aligned(16))) uint16_t Vs[64 * LDR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,11 +108,16 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
     const int nq = wsq * wsq, nk = ws * ws;
     const int nthreads = blockDim.x;
 
-    // zero the pad columns [hd, 16*DSTEPS) of both tiles once: staging never touches them
-    for (int i = tid; i < 64 * (16 * DSTEPS - hd); i += nthreads) {
-        const int r = i / (16 * DSTEPS - hd), c = hd + i % (16 * DSTEPS - hd);
+    // zero the pad columns [hd, KW) of both tiles once: staging never touches them
+    for (int i = tid; i < 64 * (KW - hd); i += nthreads) {
+        const int r = i / (KW - hd), c = hd + i % (KW - hd);
         Ks[r * LDR + c] = 0;
         Vs[r * LDR + c] = 0;
+    }
+    if constexpr (X32) {
+        // a 32-deep k-step of the second product spans TWO 16-key sub-tiles: when the last one is missing (16 / 48-key tiles) its V
+        // rows are multiplied by P = 0 -- they must be finite, so the rows no tile will write start out as zeros
+        for (int i = tid; i < 64 * (hd >> 1); i += nthreads) ((uint32_t*)Vs)[(i / (hd >> 1)) * (LDR >> 1) + i % (hd >> 1)] = 0u;
     }
 
     // this lane's query (B operand: column q = li, k = 16s + 4g .. +3)
@@ -111,12 +125,22 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
     const bool q_ok = ql < nq;
     const int qc = q_ok ? ql : 0;
     const long qrow = d * Gq * Gq + (long)(wy * wsq + qc / wsq) * Gq + wx * wsq + qc % wsq;
-    v4s qf[DSTEPS];
+    v4s qf[X32 ? 1 : DSTEPS];
+    [[maybe_unused]] bf16x8 qf8[X32 ? NQ : 1];
+    if constexpr (X32) {
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+            const int c = 32 * s + 8 * g;
+            const uint4 z{0u, 0u, 0u, 0u};
+            qf8[s] = __builtin_bit_cast(bf16x8, c < hd ? *(const uint4*)(q + qrow * ldq + (long)head * hd + c) : z);
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < DSTEPS; ++s) {
         const int c = 16 * s + 4 * g;
         if (c < hd) qf[s] = *(const v4s*)(q + qrow * ldq + (long)head * hd + c);
         else qf[s] = v4s{0, 0, 0, 0};
+    }
     }
 
     f32x4 o[DSTEPS];
@@ -200,10 +224,18 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
         for (int j = 0; j < 4; ++j) {
             sacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (j < nsub) {
+                if constexpr (X32) {
+#pragma unroll
+                    for (int s = 0; s < NQ; ++s) {
+                        const bf16x8 kf = *(const bf16x8*)(Ks + (16 * j + li) * LDR + 32 * s + 8 * g);
+                        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf8[s], sacc[j], 0, 0, 0);
+                    }
+                } else {
 #pragma unroll
                 for (int s = 0; s < DSTEPS; ++s) {
                     const v4s kf = *(const v4s*)(Ks + (16 * j + li) * LDR + 16 * s + 4 * g);
                     sacc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf, qf[s], sacc[j], 0, 0, 0);
+                }
                 }
             }
         }
@@ -256,6 +288,11 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
             // ties the fragments to the wait above: the MFMAs below consume the outputs of this (ordered) statement
             asm volatile("" : "+v"(vf[t][0]), "+v"(vf[t][1]), "+v"(vf[t][2]), "+v"(vf[t][3]));
             o[t] *= alpha;
+            if constexpr (X32) {
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(vf[t][0], vf[t][1]), cat8(pf[0], pf[1]), o[t], 0, 0, 0);  // (pf[1] = 0 on a 16-key tile)
+                if (nsub > 2) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(vf[t][2], vf[t][3]), cat8(pf[2], pf[3]), o[t], 0, 0, 0);
+                continue;
+            }
             o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][0], pf[0], o[t], 0, 0, 0);
             if (nsub > 1) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][1], pf[1], o[t], 0, 0, 0);
             if (nsub > 2) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][2], pf[2], o[t], 0, 0, 0);
@@ -364,6 +401,7 @@ __global__ __launch_bounds__(256) void k_fpn_out(const float* __restrict__ lat, 
 using namespace cvx;
 
 std::atomic<int> g_win_attn_prefetch{1};  // cvx_set_option("win_attn_prefetch", 0 / 1) -- gemm.hip
+std::atomic<int> g_win_attn_x32{1};       // cvx_set_option("win_attn_x32", 0 / 1): 16x16x32 products (0: the 16x16x16 form, A/B runs)
 
 extern "C" int cvx_sam_patches(const void* src, int mode, int D, int H, int W, int S, void* out, long ldo, hipStream_t st) {
     if (D <= 0) return 0;
@@ -393,9 +431,15 @@ extern "C" int cvx_window_attention_bf16(const void* q, long ldq, const void* k,
     // register-prefetch form: full 256-thread blocks, 16-B pieces (head_dim % 8, row starts 16-B aligned), power-of-two window
     const bool pf = g_win_attn_prefetch && threads.x == 256 && head_dim % 8 == 0 && ldkv % 8 == 0 && (window & (window - 1)) == 0 &&
                     ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
+    // 16x16x32 products: 16-B aligned 8-element pieces of Q and of the staged rows
+    const bool x32 = g_win_attn_x32 && head_dim % 8 == 0 && ldq % 8 == 0 && ((uintptr_t)q & 15) == 0;
 #define CVX_WIN_LAUNCH(DS)                                                                                                          \
     do {                                                                                                                            \
-        if (pf) hipLaunchKernelGGL((k_win_attention<DS, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
+        if (x32 && pf) hipLaunchKernelGGL((k_win_attention<DS, true, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
+                                    head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                  \
+        else if (x32) hipLaunchKernelGGL((k_win_attention<DS, false, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
+                                    head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                  \
+        else if (pf) hipLaunchKernelGGL((k_win_attention<DS, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
                                    head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                   \
         else hipLaunchKernelGGL((k_win_attention<DS, false>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo,    \
                                 head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                      \

@@ -611,12 +611,21 @@ def test_conv3_out_fused_and_dice(gpu, gold):
     ref = F.conv3d(x.float().permute(3, 0, 1, 2).unsqueeze(0), hf(w).float(), torch.tensor([b]), padding="same")[0, 0].clip(-5, 5)
     assert torch.allclose(logits.cpu(), ref, atol=1e-4, rtol=1e-4)
     assert torch.allclose(probs.cpu(), torch.sigmoid(ref), atol=1e-5)
-    # Dice sums must be exact integers given the GPU's own probabilities
+    # Dice sums must be exact integers given the GPU's own probabilities; DiceMetric's threshold and the mask's are ONE parameter
+    # (a DiceMetric(threshold != 0.5) must see the same p_hat in the fused kernel as in the stand-alone reduction)
     p = probs.cpu()
     mask = labels > -1
-    ph = (p >= 0.5).float()
-    exp = torch.tensor([float((labels.float() * ph)[mask].sum()), float(labels.float()[mask].sum()), float(ph[mask].sum())])
-    assert torch.equal(dice.cpu(), exp)
+    for thr in (0.3, 0.5):
+        if thr != 0.3:
+            dice.zero_()
+            ops.conv3_out_fused(x.to(gpu), w[0].permute(1, 2, 3, 0).reshape(27, 8).contiguous().to(gpu), b, logits, probs, labels.to(gpu),
+                                dice, D=D, H=H, W=W, mask=seg, mask_threshold=thr)
+        ph = (p >= thr).float()
+        exp = torch.tensor([float((labels.float() * ph)[mask].sum()), float(labels.float()[mask].sum()), float(ph[mask].sum())])
+        assert torch.equal(dice.cpu(), exp), thr
+        d2 = torch.zeros(3, device=gpu)
+        ops.dice_sums(probs, labels.to(gpu), d2, thr)
+        assert torch.equal(d2.cpu(), exp), thr
     # stand-alone reduction against the reference-pinned fixture
     g = gold("dice.npz")
     d2 = torch.zeros(3, device=gpu)
