@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256) void k_fpn_out(const float* __restrict__ lat, 
 using namespace cvx;
 
 std::atomic<int> g_win_attn_prefetch{1};  // cvx_set_option("win_attn_prefetch", 0 / 1) -- gemm.hip
-std::atomic<int> g_win_attn_x32{1};       // cvx_set_option("win_attn_x32", 0 / 1): 16x16x32 products (0: the 16x16x16 form, A/B runs)
+std::atomic<int> g_win_attn_x32{0};       // cvx_set_option("win_attn_x32", 0 / 1): 16x16x32 products.  Parity-green, measured 113.4 -> 115.4 ms per tomogram on
+                                          // sam_features (the kernel is not matrix-pipe bound: wider padded rows cost more than the halved MFMA count saves): off
 
 extern "C" int cvx_sam_patches(const void* src, int mode, int D, int H, int W, int S, void* out, long ldo, hipStream_t st) {
     if (D <= 0) return 0;

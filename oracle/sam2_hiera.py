@@ -136,32 +136,48 @@ def do_pool(x, stride):
     return F.max_pool2d(x.permute(0, 3, 1, 2), kernel_size=stride, stride=stride).permute(0, 2, 3, 1)
 
 
-def attention(sd, p, x, heads, q_stride):
+def _id(t):
+    return t
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def attention(sd, p, x, heads, q_stride, r=_id):
+    """``r`` rounds what the HIP path STORES in bf16 (identity: the fp32 oracle): the q/k/v rows, the probabilities fed to the
+    second product (the normaliser keeps the fp32 sum) and the attention output; weights are rounded where they are used."""
     B, H, W, _ = x.shape
-    qkv = F.linear(x, sd[p + "qkv.weight"], sd[p + "qkv.bias"]).reshape(B, H * W, 3, heads, -1)
+    qkv = r(F.linear(x, r(sd[p + "qkv.weight"]), sd[p + "qkv.bias"])).reshape(B, H * W, 3, heads, -1)
     q, k, v = qkv.unbind(2)
     if q_stride:
         q = do_pool(q.reshape(B, H, W, -1), q_stride)
         H, W = q.shape[1:3]
         q = q.reshape(B, H * W, heads, -1)
-    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
-    o = o.transpose(1, 2).reshape(B, H, W, -1)
-    return F.linear(o, sd[p + "proj.weight"], sd[p + "proj.bias"])
+    if r is _id:
+        o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+    else:
+        qt, kt, vt = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+        sc = (qt @ kt.transpose(-2, -1)) * (qt.shape[-1] ** -0.5)
+        e = torch.exp(sc - sc.amax(-1, keepdim=True))
+        o = (r(e) @ vt) / e.sum(-1, keepdim=True)
+    o = r(o.transpose(1, 2).reshape(B, H, W, -1))
+    return F.linear(o, r(sd[p + "proj.weight"]), sd[p + "proj.bias"])
 
 
-def block_forward(sd, i, spec, x):
+def block_forward(sd, i, spec, x, r=_id):
     dim, dim_out, heads, window, q_stride = spec
     p = f"trunk.blocks.{i}."
     shortcut = x
-    x = F.layer_norm(x, (dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
+    x = r(F.layer_norm(x, (dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6))
     if dim != dim_out:
-        shortcut = do_pool(F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"]), q_stride or None) if q_stride else \
-            F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"])
+        shortcut = do_pool(F.linear(x, r(sd[p + "proj.weight"]), sd[p + "proj.bias"]), q_stride or None) if q_stride else \
+            F.linear(x, r(sd[p + "proj.weight"]), sd[p + "proj.bias"])
     ws = window
     if window > 0:
         H, W = x.shape[1:3]
         x, pad_hw = window_partition(x, window)
-    x = attention(sd, p + "attn.", x, heads, q_stride)
+    x = attention(sd, p + "attn.", x, heads, q_stride, r)
     if q_stride:
         ws = window // q_stride
         H, W = shortcut.shape[1:3]
@@ -169,8 +185,8 @@ def block_forward(sd, i, spec, x):
     if window > 0:
         x = window_unpartition(x, ws, pad_hw, (H, W))
     x = shortcut + x
-    h = F.layer_norm(x, (dim_out,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
-    h = F.linear(F.gelu(F.linear(h, sd[p + "mlp.layers.0.weight"], sd[p + "mlp.layers.0.bias"])), sd[p + "mlp.layers.1.weight"],
+    h = r(F.layer_norm(x, (dim_out,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6))
+    h = F.linear(r(F.gelu(F.linear(h, r(sd[p + "mlp.layers.0.weight"]), sd[p + "mlp.layers.0.bias"]))), r(sd[p + "mlp.layers.1.weight"]),
                  sd[p + "mlp.layers.1.bias"])
     return x + h
 
@@ -183,14 +199,14 @@ def pos_embed(cfg: HieraCfg, sd, h: int, w: int) -> torch.Tensor:
     return pe.permute(0, 2, 3, 1)
 
 
-def trunk_forward(cfg: HieraCfg, sd, img: torch.Tensor) -> list[torch.Tensor]:
+def trunk_forward(cfg: HieraCfg, sd, img: torch.Tensor, r=_id) -> list[torch.Tensor]:
     """[B,3,S,S] -> stage outputs, channels-last [B,h,w,C_stage], finest first."""
-    x = F.conv2d(img, sd["trunk.patch_embed.proj.weight"], sd["trunk.patch_embed.proj.bias"], stride=4, padding=3).permute(0, 2, 3, 1)
+    x = F.conv2d(r(img), r(sd["trunk.patch_embed.proj.weight"]), sd["trunk.patch_embed.proj.bias"], stride=4, padding=3).permute(0, 2, 3, 1)
     x = x + pos_embed(cfg, sd, x.shape[1], x.shape[2])
     plan, stage_ends = cfg.block_plan()
     outs = []
     for i, spec in enumerate(plan):
-        x = block_forward(sd, i, spec, x)
+        x = block_forward(sd, i, spec, x, r)
         if i in stage_ends:
             outs.append(x)
     return outs
@@ -210,13 +226,13 @@ def sine_position_encoding(d_model: int, h: int, w: int, temperature: float = 10
     return torch.cat((py, px), dim=2).permute(2, 0, 1)
 
 
-def neck_forward(cfg: HieraCfg, sd, xs: list[torch.Tensor]):
+def neck_forward(cfg: HieraCfg, sd, xs: list[torch.Tensor], r=_id):
     """FpnNeck: (features, pos) lists, finest first, each [B,256,h,w]."""
     n = len(xs) - 1
     out, pos = [None] * (n + 1), [None] * (n + 1)
     prev = None
     for i in range(n, -1, -1):
-        lat = F.conv2d(xs[i].permute(0, 3, 1, 2), sd[f"neck.convs.{n - i}.conv.weight"], sd[f"neck.convs.{n - i}.conv.bias"])
+        lat = F.conv2d(r(xs[i]).permute(0, 3, 1, 2), r(sd[f"neck.convs.{n - i}.conv.weight"]), sd[f"neck.convs.{n - i}.conv.bias"])
         if i in cfg.fpn_top_down_levels and prev is not None:
             prev = lat + F.interpolate(prev.float(), scale_factor=2.0, mode="nearest")
         else:
@@ -226,9 +242,9 @@ def neck_forward(cfg: HieraCfg, sd, xs: list[torch.Tensor]):
     return out, pos
 
 
-def image_encoder(cfg: HieraCfg, sd, img: torch.Tensor) -> dict:
+def image_encoder(cfg: HieraCfg, sd, img: torch.Tensor, r=_id) -> dict:
     """``ImageEncoder.forward`` of the sam2 package: the dict ``SAM2.forward_features`` returns."""
-    feats, pos = neck_forward(cfg, sd, trunk_forward(cfg, sd, img))
+    feats, pos = neck_forward(cfg, sd, trunk_forward(cfg, sd, img, r), r)
     if cfg.scalp > 0:
         feats, pos = feats[: -cfg.scalp], pos[: -cfg.scalp]
     return {"vision_features": feats[-1], "vision_pos_enc": pos, "backbone_fpn": feats}
@@ -238,6 +254,16 @@ def image_encoder(cfg: HieraCfg, sd, img: torch.Tensor) -> dict:
 def forward_features(cfg: HieraCfg, sd, data: torch.Tensor) -> dict:
     """``SAM2.forward_features`` (sam2.py:190-209) on ``[b,d,3,h,w]`` float data."""
     return image_encoder(cfg, sd, resize_input(data.float(), cfg.image_size))
+
+
+@torch.no_grad()
+def forward_features_bf16_storage(cfg: HieraCfg, sd, data: torch.Tensor) -> dict:
+    """The same encoder with exact (fp32) arithmetic but every tensor the HIP path STORES in bf16 rounded to bf16: the gathered
+    patch pixels, all GEMM weights, LayerNorm outputs, q / k / v, the softmax probabilities fed to the second product, attention
+    outputs, GELU outputs and the stage outputs cast for the neck; the residual stream, the projected shortcut, accumulators,
+    softmax statistics and the FPN sums stay fp32.  It separates what bf16 storage costs from what the kernels add
+    (tests/test_gpu_sam.py), like ``oracle.dinov2.forward_features_bf16_storage`` does for the ViT."""
+    return image_encoder(cfg, sd, resize_input(data.float(), cfg.image_size), _bf)
 
 
 @torch.no_grad()

@@ -21,9 +21,21 @@ def _rows_from_grid(t):  # [D,G,G,C] -> rows
 
 @pytest.mark.parametrize("G,ws,heads,hd,pooled", [(16, 8, 2, 72, False), (16, 8, 2, 72, True), (32, 32, 1, 72, False), (8, 4, 3, 72, False),
                                                    (8, 4, 2, 72, True), (16, 16, 2, 64, False), (16, 8, 1, 96, True), (32, 16, 2, 56, False)])
-def test_window_attention(gpu, G, ws, heads, hd, pooled):
-    """softmax(q k^T / sqrt(hd)) v inside windows; pooled: queries are the 2x2 max pool of q (Hiera stage transition)."""
+@pytest.mark.parametrize("x32", [0, 1])
+def test_window_attention(gpu, G, ws, heads, hd, pooled, x32):
+    """softmax(q k^T / sqrt(hd)) v inside windows; pooled: queries are the 2x2 max pool of q (Hiera stage transition).
+    x32 = 1: both products on v_mfma_f32_16x16x32_bf16 (round 3; parity-tested, not the default: measured 2 % slower end to end)."""
+    from cryovit_amd import _lib
     from cryovit_amd.engine import ops
+
+    _lib.set_option("win_attn_x32", x32)
+    try:
+        _window_attention_case(gpu, ops, G, ws, heads, hd, pooled)
+    finally:
+        _lib.set_option("win_attn_x32", 0)
+
+
+def _window_attention_case(gpu, ops, G, ws, heads, hd, pooled):
 
     D, C = 3, heads * hd
     g = torch.Generator().manual_seed(G * 100 + ws + hd)

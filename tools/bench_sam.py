@@ -19,8 +19,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slice-batch", type=int, default=64)
     ap.add_argument("--depth", type=int, default=128)
+    ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE passed to cvx_set_option (A/B runs)")
     a = ap.parse_args()
+    from cryovit_amd import _lib
     from cryovit_amd.models import load_sam_encoder
+
+    for o in a.opt:
+        k, v = o.split("=")
+        _lib.set_option(k, int(v))
 
     dev = torch.device("cuda:0")
     enc = load_sam_encoder("SAM2", synthetic_seed=2, device=dev, slice_batch=a.slice_batch)
