@@ -47,6 +47,56 @@ def _dino_features(data: torch.Tensor, model, batch_size: int) -> np.ndarray:
     return np.concatenate(chunks, axis=1)
 
 
+class _PinnedRing:
+    """A few page-locked host buffers of one shape, handed out round-robin and returned by the writer that consumed them: the
+    403-MB device-to-host copy of tomogram i runs on a side stream while the GPU already works on tomogram i+1."""
+
+    def __init__(self):
+        self._free: dict[tuple, list[torch.Tensor]] = {}
+        self._streams: dict[torch.device, torch.cuda.Stream] = {}
+        import threading
+
+        self._lock = threading.Lock()
+
+    def take(self, shape, dtype) -> torch.Tensor:
+        with self._lock:
+            lst = self._free.setdefault((tuple(shape), dtype), [])
+            return lst.pop() if lst else torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+
+    def give(self, t: torch.Tensor) -> None:
+        with self._lock:
+            lst = self._free.setdefault((tuple(t.shape), t.dtype), [])
+            if len(lst) < 4:
+                lst.append(t)
+
+    def stream(self, device) -> torch.cuda.Stream:
+        with self._lock:
+            if device not in self._streams:
+                self._streams[device] = torch.cuda.Stream(device)
+            return self._streams[device]
+
+
+_ring = _PinnedRing()
+
+
+@torch.inference_mode()
+def _dino_features_async(data: torch.Tensor, model, batch_size: int):
+    """The fused path of ``_dino_features`` WITHOUT its synchronisation: returns ``(host fp16 tensor, event, release)``; the array is
+    valid once ``event.synchronize()`` returns, ``release()`` hands the pinned buffer back.  Used by ``_process_sample``'s pipeline
+    (the writer thread waits for the event), so the launch thread never blocks on the copy of the tomogram it has just issued."""
+    f16, _ = model.features_from_raw(data, batch_size, want_f16=True, want_cl=False)
+    host = _ring.take(f16.shape, f16.dtype)
+    cur = torch.cuda.current_stream(f16.device)
+    side = _ring.stream(f16.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        host.copy_(f16, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    f16.record_stream(side)  # the caching allocator must not hand this block out again before the copy has read it
+    return host, ev, (lambda: _ring.give(host))
+
+
 @torch.inference_mode()
 def _sam_features(data: torch.Tensor, model, batch_size: int) -> dict[str, list[np.ndarray]]:
     """SAM2 image-encoder features of one tomogram (mirror of l.67-106): every key of the encoder output except
@@ -108,8 +158,15 @@ def _process_sample(src_dir: Path, dst_dir: Path, csv_dir: Path, model, sample: 
     # decompresses tomogram i+1 while the GPU works on i, a writer thread gzips and writes i-1 (zlib drops the GIL).
     feature_fn = _sam_features if use_sam else _dino_features
 
-    def save(i, features):
-        _save_data(io.read_all_flat(tomo_dir / mine[i]), features, mine[i], result_dir)
+    def save(i, features, ready=None, release=None):
+        try:
+            if ready is not None:
+                ready.synchronize()  # the device-to-host copy of THIS tomogram (issued on a side stream) has landed
+                features = features.numpy()
+            _save_data(io.read_all_flat(tomo_dir / mine[i]), features, mine[i], result_dir)
+        finally:
+            if release is not None:
+                release()
         shapes = features.shape if not isinstance(features, dict) else {k: [f.shape for f in v] for k, v in features.items()}
         logging.info("[rank %d] %s/%s -> %s %s", rank, sample, mine[i], "sam_features" if use_sam else "dino_features", shapes)
         return mine[i]
@@ -120,8 +177,11 @@ def _process_sample(src_dir: Path, dst_dir: Path, csv_dir: Path, model, sample: 
         for i in range(len(dataset)):
             x = nxt.result()
             nxt = reader.submit(dataset.__getitem__, i + 1) if i + 1 < len(dataset) else None
-            features = feature_fn(x, model, batch_size)
-            pending.append(writer.submit(save, i, features))
+            if not use_sam and torch.is_tensor(x) and x.dim() == 3 and hasattr(model, "features_from_raw"):
+                host, ev, release = _dino_features_async(x, model, batch_size)  # no host synchronisation on the launch thread
+                pending.append(writer.submit(save, i, host, ev, release))
+            else:
+                pending.append(writer.submit(save, i, feature_fn(x, model, batch_size)))
             while len(pending) > 2:  # bound the number of 400-MB feature arrays waiting to be written
                 done.append(pending.pop(0).result())
         done += [f.result() for f in pending]

@@ -144,7 +144,20 @@ def _encoder_case(gpu, vol, cfg_name="test"):
         eng.encode(vol[d0 : d0 + 3].to(gpu), outs, d0)
     data = (vol.float() / 255.0 if vol.dtype == torch.uint8 else vol.float())[None, :, None].repeat(1, 1, 3, 1, 1)
     ref = oh.sam_features(ocfg, sd, data)
+    ref["emu_fpn"] = [t.numpy() for t in oh.forward_features_bf16_storage(ocfg, sd, data)["backbone_fpn"]]  # same storage plan, exact arithmetic
     return eng, outs, ref
+
+
+def _check_level(lvl, got, ref, emu):
+    """The ViT path's bounds (max 1e-1 / mean 1e-2 on unit-scale LayerNorm outputs) scaled to the level's mean magnitude, against the
+    fp32 oracle; and against the exact-arithmetic bf16-STORAGE emulation of the same encoder the bar of the ViT headline test: the
+    kernels sit no further from the emulation than the emulation sits from fp32 (two implementations of one storage plan)."""
+    scale = max(1.0, float(np.abs(ref).mean()))
+    e_f32, e_emu, e_store = np.abs(got - ref), np.abs(got - emu), np.abs(emu - ref)
+    stats = (lvl, scale, float(e_f32.max()), float(e_f32.mean()), float(e_emu.max()), float(e_emu.mean()), float(e_store.max()), float(e_store.mean()))
+    print("hiera level %d (scale %.2f): vs fp32 max %.3e mean %.3e; vs bf16-storage emulation max %.3e mean %.3e; emulation vs fp32 max %.3e mean %.3e" % stats)
+    assert e_f32.max() <= 0.1 * scale and e_f32.mean() <= 0.01 * scale, stats
+    assert e_emu.mean() <= e_store.mean() + 1e-4 and e_emu.max() <= 1.25 * e_store.max() + 1e-2 * scale, stats
 
 
 @pytest.mark.parametrize("H", [128, 96])
@@ -156,11 +169,8 @@ def test_hiera_encoder_vs_oracle(gpu, H):
     eng, outs, ref = _encoder_case(gpu, vol)
     assert [tuple(o.shape) for o in outs] == [(4, 256, 32, 32), (4, 256, 16, 16), (4, 256, 8, 8)]
     for lvl, (o, r) in enumerate(zip(outs, ref["backbone_fpn"])):
-        r = torch.from_numpy(r).float()
-        err = (o.float().cpu() - r).abs()
-        scale = float(r.abs().mean())
-        # bf16 GEMM operands / fp32 accumulation and residual stream: same class of tolerance as the ViT path
-        assert err.max() <= 0.15 * max(1.0, scale) and err.mean() <= 0.02 * max(1.0, scale), (lvl, float(err.max()), float(err.mean()), scale)
+        # bf16 GEMM operands / fp32 accumulation and residual stream: the ViT path's tolerance (round 3: was 1.5x / 2x of it)
+        _check_level(lvl, o.float().cpu().numpy(), r.astype(np.float32), ref["emu_fpn"][lvl])
     for lvl, r in enumerate(ref["vision_pos_enc"]):
         assert torch.equal(eng.pos_enc(lvl), torch.from_numpy(r[0]))  # input independent: bit-exact fp16
 
@@ -198,13 +208,11 @@ def test_sam_features_entry_point_hiera_l(gpu, tmp_path):
     pick = [0, 4]  # both sides of the slice batch of 4
     data = torch.from_numpy(vol[pick].astype(np.float32) / 255.0)[None, :, None].repeat(1, 1, 3, 1, 1)
     ref = oh.sam_features(oh.HIERA_L, sd, data)
+    emu = [t.numpy() for t in oh.forward_features_bf16_storage(oh.HIERA_L, sd, data)["backbone_fpn"]]
     for lvl, g in enumerate((128, 64, 32)):
         got = io.read_dataset(out, f"sam_features/backbone_fpn/{lvl}")
         assert got.dtype == np.float16 and got.shape == (5, 256, g, g)
-        r = ref["backbone_fpn"][lvl].astype(np.float32)
-        err = np.abs(got[pick].astype(np.float32) - r)
-        scale = max(1.0, float(np.abs(r).mean()))
-        assert err.max() <= 0.2 * scale and err.mean() <= 0.02 * scale, (lvl, float(err.max()), float(err.mean()), scale)
+        _check_level(lvl, got[pick].astype(np.float32), ref["backbone_fpn"][lvl].astype(np.float32), emu[lvl])
         pos = io.read_dataset(out, f"sam_features/vision_pos_enc/{lvl}")
         assert pos.dtype == np.float16 and pos.shape == (5, 256, g, g) and np.array_equal(pos[pick], ref["vision_pos_enc"][lvl])
 
