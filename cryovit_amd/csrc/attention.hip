@@ -26,12 +26,19 @@ __device__ __forceinline__ int pi_row(int r) { return (r & 0x13) | ((r & 4) << 1
 //          10-13 = timing-only ablations (10: exp2 replaced by a multiply, 11: K/V tile 0 reused, no DMA / wait / barrier,
 //          12: DMA issued but no wait / barrier, 13: wait + barrier but no DMA)
 //          3 = THREE K/V^T buffers: tile j+2 is issued in iteration j and waited for with a counted vmcnt(4)
+//          8 / 9 = variant 7 with EIGHT waves per workgroup (256 query rows share every K / V^T tile: half the LDS-DMA instructions
+//          and half the L2 -> LDS bytes per query row).  Two such workgroups per CU keep four waves per SIMD, and their 2 x 48 KB of
+//          LDS have room for a THIRD tile buffer (8: two tiles of look-ahead behind a counted wait; 9: two buffers, for A/B runs) --
+//          the three-buffer form of the 4-wave kernel (variant 3) paid for its buffer with the fourth wave per SIMD.
 template <int VARIANT>
-__global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __restrict__ qk, long ldqk,
+__global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS) void k_attention(const uint16_t* __restrict__ qk, long ldqk,
                                                            const uint16_t* __restrict__ vt, uint16_t* __restrict__ out,
                                                            long ldo, int heads, int ntok, int ntp, int kp, int C, int nqb,
                                                            int xcd_remap) {
-    constexpr int NBUF = VARIANT == 3 ? 3 : 2;
+    constexpr int NW = (VARIANT == 8 || VARIANT == 9) ? 8 : 4;       // waves per workgroup, 32 query rows each
+    constexpr int NT = NW * 64, QB = NW * 32;                        // threads, query rows per workgroup
+    constexpr int PPT = 512 / NT;                                    // 16-B pieces per thread and tile (K and V^T alike)
+    constexpr int NBUF = (VARIANT == 3 || VARIANT == 8) ? 3 : 2;
     __shared__ __attribute__((aligned(16))) char smem[NBUF * 2 * ATT_TILE_BYTES];  // [buf][K | V^T]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     const uint16_t* Vp = vt + ((long)(slice * heads + head) * 64) * kp;
 
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * QB + wave * 32;
     const int qrow = min(q0 + r, ntp - 1);  // rows past the slice are clamped for loads, never stored
     const bool wave_idle = VARIANT != 1 && q0 >= ntok;  // (variant 1 keeps the old behaviour for A/B runs)
 
@@ -76,8 +83,8 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     // as long as the row maxima of the tile stay within DEFER (log2 units) of the value subtracted.  The VALU, not the
     // matrix pipe, bounds this kernel at head_dim 64 (PMC: VALU active 73 % of SIMD cycles, MFMA 39 %); the 32 fused
     // multiply-adds per tile this removes were 15 % of its vector instructions, for 2 more MFMAs on the idle pipe.
-    constexpr bool AUG = VARIANT == 6 || VARIANT == 7;
-    constexpr bool PSUM_TRIGGER = VARIANT == 7;  // the maximum is only looked at in tile 0; later tiles watch their probability sums
+    constexpr bool AUG = VARIANT == 6 || VARIANT == 7 || VARIANT == 8 || VARIANT == 9;
+    constexpr bool PSUM_TRIGGER = VARIANT == 7 || VARIANT == 8 || VARIANT == 9;  // the maximum is only looked at in tile 0; later tiles watch their probability sums
     constexpr float DEFER = 3.0f;  // p <= 2^3 before a row's maximum is raised (bf16 P is floating point: same relative precision)
     bf16x8 kaug, qaug;
     [[maybe_unused]] float m_used = 0.f;  // what is currently subtracted (exactly representable in bf16)
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     uint32_t koffs[2], voffs[2];
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-        const int c = jj * ATT_THREADS + tid;
+        const int c = (jj < PPT ? jj : 0) * NT + tid;  // (PPT = 1: the second entry is unused)
         const int srow = c >> 3, schunk = ((c & 7) ^ ((srow >> 1) & 7)) << 3;
         koffs[jj] = (uint32_t)(srow * ldqk + schunk) * 2u;
         voffs[jj] = (uint32_t)(srow * kp + schunk) * 2u;
@@ -100,13 +107,18 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
     // A query block whose rows all belong to wave 0 (1029 tokens = 8 x 128 + 5: every ninth block) runs as ONE wave: waves 1-3
     // leave at once (a hardware barrier only counts the waves still alive) and wave 0 issues their DMA pieces too -- their wave
     // slots go back to the CU instead of idling through 17 tiles of barriers.
-    const bool lone = AUG && qb * 128 + 32 >= ntok;  // (uniform per workgroup)
+    const bool lone = AUG && qb * QB + 32 >= ntok;  // (uniform per workgroup)
     if (lone && wave != 0) return;
     auto issue = [&](int j, int buf) {
         const uint32_t kt = lds_addr(smem) + buf * 2 * ATT_TILE_BYTES + wave * 1024;
         const long kv0 = (long)j * KV_TILE;
-        glds16_saddr2<ATT_THREADS * 16>(Kp + kv0 * ldqk, koffs[0], koffs[1], kt);
-        glds16_saddr2<ATT_THREADS * 16>(Vp + kv0, voffs[0], voffs[1], kt + ATT_TILE_BYTES);
+        if constexpr (PPT == 2) {
+            glds16_saddr2<NT * 16>(Kp + kv0 * ldqk, koffs[0], koffs[1], kt);
+            glds16_saddr2<NT * 16>(Vp + kv0, voffs[0], voffs[1], kt + ATT_TILE_BYTES);
+        } else {
+            glds16_saddr(Kp + kv0 * ldqk, koffs[0], kt);
+            glds16_saddr(Vp + kv0, voffs[0], kt + ATT_TILE_BYTES);
+        }
         if (lone) {
             // the pieces of the departed waves: wave w2's thread sits 8 w2 tile rows below this one, same chunk, and its swizzle
             // term (row >> 1) & 7 differs by 4 w2 & 7, i.e. the 16-B chunk index flips bit 2 for odd w2 (ldqk and kp are multiples
@@ -115,11 +127,16 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
             uint32_t k0 = koffs[0], k1 = koffs[1], v0 = voffs[0], v1 = voffs[1];
             asm volatile("" : "+v"(k0), "+v"(k1), "+v"(v0), "+v"(v1));
 #pragma unroll 1
-            for (int w2 = 1; w2 < 4; ++w2) {
+            for (int w2 = 1; w2 < NW; ++w2) {
                 const uint32_t fl = (w2 & 1) ? 64u : 0u;
                 const uint32_t dk = (uint32_t)(w2 * 16) * (uint32_t)ldqk, dv = (uint32_t)(w2 * 16) * (uint32_t)kp;
-                glds16_saddr2<ATT_THREADS * 16>(Kp + kv0 * ldqk, (k0 + dk) ^ fl, (k1 + dk) ^ fl, kt + w2 * 1024);
-                glds16_saddr2<ATT_THREADS * 16>(Vp + kv0, (v0 + dv) ^ fl, (v1 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
+                if constexpr (PPT == 2) {
+                    glds16_saddr2<NT * 16>(Kp + kv0 * ldqk, (k0 + dk) ^ fl, (k1 + dk) ^ fl, kt + w2 * 1024);
+                    glds16_saddr2<NT * 16>(Vp + kv0, (v0 + dv) ^ fl, (v1 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
+                } else {
+                    glds16_saddr(Kp + kv0 * ldqk, (k0 + dk) ^ fl, kt + w2 * 1024);
+                    glds16_saddr(Vp + kv0, (v0 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
+                }
             }
         }
     };
@@ -149,8 +166,11 @@ __global__ __launch_bounds__(ATT_THREADS) void k_attention(const uint16_t* __res
         if (!PSUM_TRIGGER || !redo) {
         if (!ABL_NOSYNC || j == 0) {
             // tile j landed (with three buffers tile j+1 may stay in flight); every wave is done with tile j-1
-            if (NBUF == 3 && j + 1 < nkv) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (a wave's own pieces of tile j+1 are its 2 PPT youngest entries -- 2 PPT NW when it issues for the whole workgroup)
+            if (NBUF == 3 && j + 1 < nkv) {
+                if (lone) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT * NW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
         if (NBUF == 3) {
@@ -525,8 +545,8 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     // Variant 6's single-wave query blocks derive the departed waves' DMA offsets by XOR-ing 64 into wave 0's own, which is the other
     // waves' row term only while a K row's byte pitch is a multiple of 128 (ldqk % 64 == 0: every DINOv2 width).  Other leading
     // dimensions take the general kernel (variant 0: a running maximum per tile).
-    if ((variant == 6 || variant == 7) && ldqk % 64 != 0) variant = 0;
-    const int rows_per_block = variant == 4 ? 192 : variant == 5 ? 256 : 128;
+    if ((variant == 6 || variant == 7 || variant == 8 || variant == 9) && ldqk % 64 != 0) variant = 0;
+    const int rows_per_block = variant == 4 ? 192 : (variant == 5 || variant == 8 || variant == 9) ? 256 : 128;
     const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;
     if (nblk > 0x7fffffff) return cvx_fail("attention: grid too large");
@@ -535,7 +555,9 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     void (*k)(const uint16_t*, long, const uint16_t*, uint16_t*, long, int, int, int, int, int, int, int);
     switch (variant) {
         case 7: k = k_attention<7>; break;
-#ifdef CVX_ABLATION  // earlier schedules (parity-tested on the ablation build) and timing-only ones with garbage output
+#ifdef CVX_ABLATION  // earlier / rejected schedules (parity-tested on the ablation build) and timing-only ones with garbage output
+        case 8: k = k_attention<8>; break;  // 8-wave workgroups, three buffers: measured 1.001 -> 1.123 ms per layer
+        case 9: k = k_attention<9>; break;  // 8-wave workgroups, two buffers: 1.082 ms
         case 1: k = k_attention<1>; break;
         case 3: k = k_attention<3>; break;
         case 6: k = k_attention<6>; break;
@@ -554,7 +576,7 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
         return cvx_check_launch();
     }
 #endif
-    hipLaunchKernelGGL(k, grid, dim3(ATT_THREADS), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo, heads,
+    hipLaunchKernelGGL(k, grid, dim3((variant == 8 || variant == 9) ? 512 : ATT_THREADS), 0, st, (const uint16_t*)qk, ldqk, (const uint16_t*)vt, (uint16_t*)out, ldo, heads,
                        ntok, ntp, kp, heads * 64, nqb, xcd_remap);
     return cvx_check_launch();
 }

@@ -810,7 +810,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
         g_ln_policy = value;
     }
     else if (!strcmp(name, "attn_variant")) {
-        if (!one_of({0, 7}) && !(abl && one_of({1, 3, 4, 5, 6, 10, 11, 12, 13})))
+        if (!one_of({0, 7}) && !(abl && one_of({1, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13})))
             return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");
         g_attn_variant = value;
     } else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value != 0;

@@ -251,7 +251,7 @@ def attn_variant(request):
     _lib.set_option("attn_variant", 7)  # the default
 
 
-@pytest.mark.parametrize("attn_variant", [0, 3, 4, 5, 6, 7], indirect=True)
+@pytest.mark.parametrize("attn_variant", [0, 3, 4, 5, 6, 7, 8, 9], indirect=True)
 @pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1)])
 def test_attention(gpu, nt, slices, heads, attn_variant):
     from cryovit_amd.engine import ops
@@ -306,7 +306,7 @@ def test_attention_odd_leading_dimension(gpu, pad):
 
 
 @pytest.mark.parametrize("spike", [4.0, 9.0, 60.0, -60.0])
-@pytest.mark.parametrize("attn_variant", [0, 4, 6, 7], indirect=True)
+@pytest.mark.parametrize("attn_variant", [0, 4, 6, 7, 8, 9], indirect=True)
 def test_attention_forced_rescale(gpu, attn_variant, spike):
     """One key row spiked against one query so the running max jumps in a late tile (rare-branch test).  spike 60: the jump
     is far above the deferred-maximum threshold of variant 6 (its raise-and-rescale branch) and beyond what one exp2 can hold
