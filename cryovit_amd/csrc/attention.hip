@@ -46,7 +46,8 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
     // which stream the SAME K / V^T -- are placed on one XCD, back to back in its dispatch sequence, so a K/V tile is an
     // L2 miss once and an L2 hit for the other query blocks.  (Placement only changes speed, never results.)
     int qb, pair;
-    if (xcd_remap) {
+    const bool prio_qk = (xcd_remap & 2) != 0, prio_pv = (xcd_remap & 4) != 0;  // s_setprio 1 around the wave's MFMA blocks (cvx_set_option "attn_mfma_prio": bit 0 S^T, bit 1 O^T)
+    if (xcd_remap & 1) {
         const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
         pair = (w / nqb) * 8 + xcd;
         qb = w % nqb;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
         auto compute_s = [&]() {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
+            if (prio_qk) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 if constexpr (AUG) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kaug, qaug, s[t], 0, 0, 0);  // -m_used for every key
@@ -204,6 +206,7 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
                     s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
                 }
             }
+            if (prio_qk) __builtin_amdgcn_s_setprio(0);
             // ---- mask keys >= ntok (last tile only; wave-uniform test) ----
             if (kv0 + KV_TILE > ntok) {
 #pragma unroll
@@ -327,6 +330,7 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
         }  // !AUG
 
         // ---- O^T[dt] += V^T[dt] P^T : accumulator registers 8s..8s+7 of S^T[t] are k-step s of the B operand ----
+        if (prio_pv) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -340,6 +344,7 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
             }
+        if (prio_pv) __builtin_amdgcn_s_setprio(0);
     }
 
     // ---- normalise and store: lane (r,h) holds O[q0+r][32dt + 8g + 4h + (0..3)] in regs 4g..4g+3 ----
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(NW * 64) void k_attention64(const uint16_t* __restr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int qb, pair;
-    if (xcd_remap) {
+    if (xcd_remap & 1) {
         const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3;
         pair = (w / nqb) * 8 + xcd;
         qb = w % nqb;
@@ -535,6 +540,8 @@ using namespace cvx;
 
 std::atomic<int> g_attn_variant{7};     // cvx_set_option("attn_variant"); 7 = maximum subtracted inside the product, re-anchoring triggered by the probability sums (default); 6 = by the tile maxima
 std::atomic<int> g_attn_xcd_remap{1};   // cvx_set_option("attn_xcd_remap")
+std::atomic<int> g_attn_mfma_prio{2};   // cvx_set_option("attn_mfma_prio"): s_setprio 1 around the wave's MFMA blocks (bit 0: S^T, bit 1: O^T).  Measured per layer:
+                                        // 0: 1.028 ms, 1: 1.018, 2: 0.999 (default), 3: 1.003 -- the O^T MFMAs wait behind other waves' softmax VALU otherwise
 
 extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
                                   int ntok, int ntp, int kp, hipStream_t st) {
@@ -550,7 +557,7 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;
     if (nblk > 0x7fffffff) return cvx_fail("attention: grid too large");
-    const int xcd_remap = ((long)heads * slices) % 8 == 0 && g_attn_xcd_remap;
+    const int xcd_remap = (((long)heads * slices) % 8 == 0 && g_attn_xcd_remap ? 1 : 0) | ((g_attn_mfma_prio.load() & 3) << 1);
     dim3 grid((unsigned)nblk);
     void (*k)(const uint16_t*, long, const uint16_t*, uint16_t*, long, int, int, int, int, int, int, int);
     switch (variant) {

@@ -32,7 +32,8 @@ res = {}
 for r in range(args.rounds):
     for v in [int(x) for x in args.variants.split(",")]:
         _lib.set_option("attn_variant", v % 100)
-        _lib.set_option("attn_xcd_remap", 0 if v >= 100 else 1)  # variant + 100 = same kernel without the XCD block remap
+        _lib.set_option("attn_xcd_remap", 0 if 100 <= v < 200 else 1)  # variant + 100 = same kernel without the XCD block remap
+        _lib.set_option("attn_mfma_prio", v // 200)                   # variant + 200 p = s_setprio 1 around the MFMA blocks (p bit 0: S^T, bit 1: O^T)
         ops.attention(qk, vt, out, slices=slices, heads=heads, ntok=nt, ntp=ntp, kp=kp)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
