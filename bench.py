@@ -231,7 +231,12 @@ def other_configs(dev, vol) -> dict:
     eng = UNet3DEngine(model.state_dict(), dev)
     volf = vol.float() / 255.0
     ms = timed(lambda: eng.forward(volf))
-    out["UNet3D baseline (models/unet3d.py) forward, one raw tomogram"] = {"ms": round(ms, 3), "voxels_per_s": voxels / ms * 1e3}
+    fl = eng.flops(*vol.shape)
+    out["UNet3D baseline (models/unet3d.py) forward, one raw tomogram"] = {
+        "ms": round(ms, 3), "voxels_per_s": voxels / ms * 1e3, "algorithmic_tflop": fl / 1e12, "tflops": fl / ms / 1e9,
+        "frac_of_mfma_peak": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
+        # every activation is written once and read once or twice by the next layer: the forward is HBM-bound, not MFMA-bound
+        "roofline_note": "HBM-bound (full-resolution 32-channel fp16 activations: 2.1 GB per layer pair); see profiles/r02_unet_kernel_stats.csv"}
     return out
 
 

@@ -105,6 +105,8 @@ SIGNATURES = {
     "cvx_concat_channels_f16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "cvx_pointwise_out_f16": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "cvx_groupnorm_act_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "cvx_groupnorm_act_strided_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int,
+                                              c_void_p]),
     "cvx_layernorm_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
     "cvx_attention_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cvx_preprocess_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -397,9 +397,12 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const float* __restrict__ pa
     }
 }
 
+// out rows may be wider than C (`ldo`: the result lands in a column block of a wider channels-last buffer -- the concatenated input
+// of a UNet3D synthesis block, written in place instead of through a copy kernel); out2 (nullable): a second, dense copy
 template <int ACT>
 __global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x, const float* __restrict__ coef,
-                                                  uint16_t* __restrict__ out, long nvox, int C, long vox_per_block) {
+                                                  uint16_t* __restrict__ out, long ldo, uint16_t* __restrict__ out2, long nvox, int C,
+                                                  long vox_per_block) {
     const int tid = threadIdx.x;
     const int cpt = C >> 3;
     const int cc = tid % cpt, vsub = tid / cpt, vstride = 256 / cpt;
@@ -429,12 +432,23 @@ __global__ __launch_bounds__(256) void k_gn_apply(const uint16_t* __restrict__ x
     for (; v + 3 * vstride < v1; v += 4 * vstride) {
         const uint4 u0 = ld_stream16(x + v * C + co), u1 = ld_stream16(x + (v + vstride) * C + co);
         const uint4 u2 = ld_stream16(x + (v + 2 * vstride) * C + co), u3 = ld_stream16(x + (v + 3 * vstride) * C + co);
-        *(uint4*)(out + v * C + co) = norm(u0);
-        *(uint4*)(out + (v + vstride) * C + co) = norm(u1);
-        *(uint4*)(out + (v + 2 * vstride) * C + co) = norm(u2);
-        *(uint4*)(out + (v + 3 * vstride) * C + co) = norm(u3);
+        const uint4 n0 = norm(u0), n1 = norm(u1), n2 = norm(u2), n3 = norm(u3);
+        *(uint4*)(out + v * ldo + co) = n0;
+        *(uint4*)(out + (v + vstride) * ldo + co) = n1;
+        *(uint4*)(out + (v + 2 * vstride) * ldo + co) = n2;
+        *(uint4*)(out + (v + 3 * vstride) * ldo + co) = n3;
+        if (out2) {
+            *(uint4*)(out2 + v * C + co) = n0;
+            *(uint4*)(out2 + (v + vstride) * C + co) = n1;
+            *(uint4*)(out2 + (v + 2 * vstride) * C + co) = n2;
+            *(uint4*)(out2 + (v + 3 * vstride) * C + co) = n3;
+        }
     }
-    for (; v < v1; v += vstride) *(uint4*)(out + v * C + co) = norm(ld_stream16(x + v * C + co));
+    for (; v < v1; v += vstride) {
+        const uint4 n0 = norm(ld_stream16(x + v * C + co));
+        *(uint4*)(out + v * ldo + co) = n0;
+        if (out2) *(uint4*)(out2 + v * C + co) = n0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -608,8 +622,10 @@ extern "C" int cvx_features_to_channels_last(const void* feats_f16, void* out_cl
 }
 
 static int groupnorm_impl(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C, int G, float eps,
-                          int act, hipStream_t st) {
+                          int act, hipStream_t st, long ldo = 0, void* out2 = nullptr) {
     if (nvox <= 0) return 0;
+    if (ldo == 0) ldo = C;
+    if (ldo < C || ldo % 8) return cvx_fail("groupnorm: the output leading dimension must be >= C and a multiple of 8");
     const int cpt = C / 8;
     if (C % 8 || cpt > 256 || C % G || G > CVX_GN_MAX_GROUPS)
         return cvx_fail("groupnorm: C must be a multiple of 8, <= 2048, divisible by G, G <= 512");
@@ -632,8 +648,8 @@ static int groupnorm_impl(const void* x, const float* w, const float* b, void* o
     if (rc) return rc;
     const long vox_per_block = 8L * vstride;                     // 8 voxels per thread, four 16-B loads in flight
     const unsigned nblk = (unsigned)((nvox + vox_per_block - 1) / vox_per_block);
-    if (act) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, nvox, C, vox_per_block);
-    else hipLaunchKernelGGL(k_gn_apply<0>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, nvox, C, vox_per_block);
+    if (act) hipLaunchKernelGGL(k_gn_apply<1>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, ldo, (uint16_t*)out2, nvox, C, vox_per_block);
+    else hipLaunchKernelGGL(k_gn_apply<0>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)x, coef, (uint16_t*)out, ldo, (uint16_t*)out2, nvox, C, vox_per_block);
     return cvx_check_launch();
 }
 
@@ -646,4 +662,11 @@ extern "C" int cvx_groupnorm_act_f16(const void* x, const float* w, const float*
                                       int G, float eps, int act, hipStream_t st) {
     if (act != 0 && act != 1) return cvx_fail("groupnorm_act: act is 0 (none) or 1 (GELU)");
     return groupnorm_impl(x, w, b, out, stats, nvox, C, G, eps, act, st);
+}
+
+extern "C" int cvx_groupnorm_act_strided_f16(const void* x, const float* w, const float* b, void* out, long ldo, void* out2_dense, float* stats,
+                                              long nvox, int C, int G, float eps, int act, hipStream_t st) {
+    if (act != 0 && act != 1) return cvx_fail("groupnorm_act_strided: act is 0 (none) or 1 (GELU)");
+    if (!out) return cvx_fail("groupnorm_act_strided: null output");
+    return groupnorm_impl(x, w, b, out, stats, nvox, C, G, eps, act, st, ldo, out2_dense);
 }

@@ -232,6 +232,19 @@ def groupnorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tens
          stats.data_ptr(), nvox, Cdim, G, eps)
 
 
+def groupnorm_into(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, out: torch.Tensor, col0: int, ldo: int, stats: torch.Tensor, *, nvox: int,
+                   Cdim: int, G: int, eps: float, act: int = 0, out2=None) -> None:
+    """GroupNorm (+ GELU) whose result lands in columns [col0, col0 + C) of a wider channels-last fp16 buffer with rows `ldo` elements
+    apart (flat tensor `out`); `out2`: optional second dense [nvox, C] copy."""
+    dev = _dev_check(x, w, b, out, stats, out2)
+    if stats.dtype != torch.float32 or stats.numel() < gn_stats_size(G):
+        raise _lib.CvxError(f"groupnorm: stats must be fp32 with >= {gn_stats_size(G)} elements (2*G*(1+CVX_GN_BLOCKS))")
+    if out.dtype != torch.float16 or col0 % 8 or col0 + Cdim > ldo or out.numel() < nvox * ldo:
+        raise _lib.CvxError("groupnorm_into: out fp16 with >= nvox*ldo elements, col0 a multiple of 8, col0 + C <= ldo")
+    call(dev, "cvx_groupnorm_act_strided_f16", _lib.load().cvx_groupnorm_act_strided_f16, x.data_ptr(), w.data_ptr(), b.data_ptr(),
+         out.data_ptr() + 2 * col0, ldo, _p(out2), stats.data_ptr(), nvox, Cdim, G, eps, act)
+
+
 _dice_scratch = {}
 
 

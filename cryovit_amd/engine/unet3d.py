@@ -86,6 +86,11 @@ class UNet3DEngine:
         self.stats = torch.zeros(ops.gn_stats_size(gmax), dtype=torch.float32, device=self.device)
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.device)
         self._bufs: dict = {}
+        # torch.cat of a synthesis block: True = dense tensors + cvx_concat_channels_f16 (default); False = both InstanceNorm passes write
+        # straight into their column block of the concatenated buffer (cvx_groupnorm_act_strided_f16).  Measured on one board, A/B in one
+        # process (tools/bench_unet.py --ab): 15.1 ms with the copy kernel, 15.9 ms in place -- half-row writes at a doubled row pitch and
+        # the second (dense) copy of the skip tensor cost more than the 1-ms copy kernel they remove.
+        self.concat_copy = True
 
     def _buf(self, name: str, rows: int, ch: int) -> torch.Tensor:
         key = (name, rows, ch)
@@ -117,13 +122,22 @@ class UNet3DEngine:
         xin[..., 0] = vol.to(torch.float16)
         skips = []
         d, h, w = D, H, W
+        nlev = len(self.analysis)
         for i, B in enumerate(self.analysis):
             nv = d * h * w
             t = self._conv(x, B["c1"], f"a{i}c1", d, h, w)
             t = self._norm_gelu(t, B["n1"], f"a{i}n1", nv, B["c1"]["cout"])
             t = self._conv(t, B["c2"], f"a{i}c2", d, h, w)
-            skip = self._norm_gelu(t, B["n2"], f"a{i}skip", nv, B["c2"]["cout"])
-            skips.append((skip, B["c2"]["cout"]))
+            # the skip tensor is written TWICE by its InstanceNorm + GELU pass: dense (input of the pooling convolution) and straight
+            # into its column block of the synthesis block's concatenated input (torch.cat of unet3d.py:64 without a copy kernel)
+            cs, cu = B["c2"]["cout"], self.synthesis[nlev - 1 - i]["up"]["cout"]
+            cat = self._buf(f"s{nlev - 1 - i}cat", nv, cu + cs)
+            skip = self._buf(f"a{i}skip", nv, cs)
+            if self.concat_copy:  # round 2's form (A/B: UNet3DEngine.concat_copy = True): dense skip, cvx_concat_channels_f16 later
+                ops.groupnorm(t, B["n2"]["w"], B["n2"]["b"], skip, self.stats, nvox=nv, Cdim=cs, G=cs, eps=1e-3, act=1)
+            else:
+                ops.groupnorm_into(t, B["n2"]["w"], B["n2"]["b"], cat, cu, cu + cs, self.stats, nvox=nv, Cdim=cs, G=cs, eps=1e-3, act=1, out2=skip)
+            skips.append((cat, cs, skip))
             p = self._buf(f"a{i}pool", nv // 8, B["pool"]["cout"])
             ops.conv2s2(skip, B["pool"]["w"], B["pool"]["b"], p, self.zero_page, Cin=B["pool"]["cin"], D=d, H=h, W=w, cout=B["pool"]["cout"], act=0)
             d, h, w = d // 2, h // 2, w // 2
@@ -141,10 +155,13 @@ class UNet3DEngine:
             ops.gemm(EPI_CONVT, a2, U["w"], upb, U["b"], m=nv, n=8 * U["cout"], H=h, W=w, cout=U["cout"], act=0, ldc=U["cout"], convt_up_z=1)
             d, h, w = 2 * d, 2 * h, 2 * w
             nv = d * h * w
-            un = self._norm_gelu(upb, S["nu"], f"s{i}upn", nv, U["cout"])
-            skip, cs = skips.pop()
-            cat = self._buf(f"s{i}cat", nv, U["cout"] + cs)
-            ops.concat_channels(un, skip, cat, nvox=nv, Ca=U["cout"], Cb=cs)
+            cat, cs, skip = skips.pop()  # (its skip half was filled by the analysis path)
+            if self.concat_copy:
+                un = self._norm_gelu(upb, S["nu"], f"s{i}upn", nv, U["cout"])
+                ops.concat_channels(un, skip, cat, nvox=nv, Ca=U["cout"], Cb=cs)
+            else:
+                ops.groupnorm_into(upb, S["nu"]["w"], S["nu"]["b"], cat, 0, U["cout"] + cs, self.stats, nvox=nv, Cdim=U["cout"], G=U["cout"],
+                                   eps=1e-3, act=1)
             Lp = S["lin"]
             lin = self._buf(f"s{i}lin", nv, Lp["cout"])
             a2 = torch.as_strided(cat, (ops.alloc_rows(nv), Lp["cin"]), (Lp["cin"], 1))
@@ -157,6 +174,22 @@ class UNet3DEngine:
         logits = torch.empty(D, H, W, dtype=torch.float32, device=self.device) if want_logits else None
         ops.pointwise_out(x, self.out_w, self.out_b, logits, probs, nvox=nv, Cdim=self.out_c)
         return (probs, logits) if want_logits else probs
+
+    def flops(self, D: int, H: int, W: int) -> float:
+        """Algorithmic FLOPs (2 * MACs of the convolutions, transposed convolutions and 1x1x1 layers; norms and GELUs excluded -- the
+        accounting of SURVEY.md s.8d) of one forward over a [D, H, W] volume (axes padded to multiples of 16)."""
+        D, H, W = (PAD * math.ceil(v / PAD) for v in (D, H, W))
+        nv, f = D * H * W, 0.0
+        conv = lambda L, n: 2.0 * 27 * L["cin"] * L["cout"] * n  # noqa: E731
+        for B in self.analysis:
+            f += conv(B["c1"], nv) + conv(B["c2"], nv) + 2.0 * 8 * B["pool"]["cin"] * B["pool"]["cout"] * (nv // 8)
+            nv //= 8
+        f += conv(self.bottom["c1"], nv) + conv(self.bottom["c2"], nv)
+        for S in self.synthesis:
+            f += 2.0 * S["up"]["cin"] * 8 * S["up"]["cout"] * nv
+            nv *= 8
+            f += 2.0 * S["lin"]["cin"] * S["lin"]["cout"] * nv + conv(S["c"], nv)
+        return f + 2.0 * self.out_c * nv
 
     @torch.inference_mode()
     def forward(self, vol: torch.Tensor) -> torch.Tensor:

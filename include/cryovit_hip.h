@@ -201,6 +201,11 @@ int cvx_groupnorm_f16(const void* x, const float* w, const float* b, void* out, 
  * nn.InstanceNorm3d(C, eps, affine=True) of the UNet3D baseline (models/unet3d.py:19-25,127-140). */
 int cvx_groupnorm_act_f16(const void* x, const float* w, const float* b, void* out, float* stats, long nvox, int C,
                            int G, float eps, int act, hipStream_t stream);
+/* The same writing into a column block of a WIDER channels-last buffer: out points at the block's first column, rows are ldo
+ * elements apart (ldo >= C, a multiple of 8); out2_dense (nullable) receives a second, dense [nvox][C] copy.  torch.cat along the
+ * channels of a UNet3D synthesis block (models/unet3d.py:64) then costs no pass of its own: both of its inputs are outputs of this op. */
+int cvx_groupnorm_act_strided_f16(const void* x, const float* w, const float* b, void* out, long ldo, void* out2_dense, float* stats,
+                                   long nvox, int C, int G, float eps, int act, hipStream_t stream);
 
 /* Last layer of the head at full resolution, channels-last fp16 in[D][H][W][8]:
  *   conv3x3x3(8->1, w fp32 [27][8] tap-major) + bias, clip(+-5) -> logits fp32 (nullable), sigmoid -> probs fp32

@@ -122,6 +122,10 @@ def test_unet3d_narrow_against_reference_fixture(gpu, gold):
     assert float(err.max()) <= 1.5e-2 and float(err.mean()) <= 1.5e-3
     agree = ((probs >= 0.5) == (want >= 0.5)).float().mean()
     assert float(agree) >= 0.999
+    # torch.cat written in place by the two InstanceNorm passes (cvx_groupnorm_act_strided_f16) == dense tensors + copy kernel, bit for bit
+    model.engine().concat_copy = False
+    assert torch.equal(model(Batch()).cpu(), probs)
+    model.engine().concat_copy = True
 
 
 def test_unet3d_reference_widths_runs_and_matches_oracle(gpu):

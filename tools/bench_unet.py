@@ -17,14 +17,17 @@ with torch.no_grad():
         p.copy_(torch.randn(p.shape, generator=g) * ((2.0 / max(1, p[0].numel())) ** 0.5 if p.dim() > 1 else 0.1) + (1.0 if p.dim() == 1 and name.endswith(("1.weight", "4.weight")) else 0.0))
 eng = UNet3DEngine(model.state_dict(), dev)
 vol = torch.rand(128, 512, 512, device=dev)
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-eng.forward(vol)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps):
-    p = eng.forward(vol)
-e1.record()
-torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / reps
-print(f"UNet3D forward: {ms:.3f} ms = {vol.numel() / ms / 1e6:.2f} Gvoxel/s; mean prob {float(p.mean()):.4f}")
+reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
+for copy in ((False, True, False, True) if "--ab" in sys.argv else (False,)):  # --ab: in-place concatenation vs round 2's copy kernel
+    eng.concat_copy = copy
+    eng.forward(vol)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        p = eng.forward(vol)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f"UNet3D forward ({'concat copy kernel' if copy else 'concatenation in place'}): {ms:.3f} ms = {vol.numel() / ms / 1e6:.2f} Gvoxel/s = "
+          f"{eng.flops(*vol.shape) / ms / 1e9:.0f} TFLOP/s; mean prob {float(p.mean()):.4f}")
