@@ -679,6 +679,10 @@ static int launch_256_split(const uint16_t* A, long lda, const uint16_t* Wt, lon
             int rc = launch_256<Epi, false>(A, lda, Wt, ldw, m_main, Npad, Kpad, epi, st);
             if (rc) return rc;
             // the tail is a handful of tiles on an otherwise idle chip: latency-bound, so more, smaller workgroups finish sooner
+            if (g_tail_tile == 2 && (M - m_main) / 256 * (Npad / 256) * 16 <= 1024)
+                // 64 x 64 tiles, 32 KB of LDS each: three workgroups per CU.  The tail is LATENCY-bound (one K tile of look-ahead, a
+                // K tile per DMA round trip): co-resident workgroups overlap each other's waits
+                return launch_nreg<TileCfg<64, 64, 1>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
             if (g_tail_tile && (M - m_main) / 256 * (Npad / 256) * 8 <= 256)  // (8 small tiles per 256 x 256 tile: one round at most)
                 return launch_nreg<TileCfg<64, 128, 1>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
             return launch_nreg<TileCfg<128, 128, 2>>(A + m_main * lda, lda, Wt, ldw, M - m_main, Npad, Kpad, epi.shifted(m_main), st);
@@ -790,7 +794,10 @@ extern "C" int cvx_set_option(const char* name, int value) {
         if (!one_of({0, 1, 2})) return cvx_fail("set_option: gemm_tail_split is 0 (off), 1 (on; residual epilogues only for K >= 2048) or 2 (always)");
         g_tail_split = value;
     }
-    else if (!strcmp(name, "gemm_tail_tile")) g_tail_tile = value != 0;
+    else if (!strcmp(name, "gemm_tail_tile")) {
+        if (!one_of({0, 1, 2})) return cvx_fail("set_option: gemm_tail_tile is 0 (128 x 128), 1 (64 x 128) or 2 (64 x 64 tiles)");
+        g_tail_tile = value;
+    }
     else if (!strcmp(name, "gemm_resid_reverse")) g_resid_reverse = value != 0;
     else if (!strcmp(name, "gemm_resid_stagger")) {
         if (value < 0 || value > 1000000) return cvx_fail("set_option: gemm_resid_stagger is a cycle count in [0, 1e6]");

@@ -49,6 +49,7 @@ cases = {
     "qk   LN   ": (lambda: ops.gemm(EPI_BF16, a_c, w["qk"], o_qk, bc["qk"], m=M, n=2 * C, ln_rowstat=rowstat), 2 * C * C),
     "v    plain": (lambda: ops.gemm(EPI_VT, a_c, w["v"], vt, bias["v"], m=M, n=C, heads=heads, ntp=ntp, kp=kp, ldc=0), C * C),
     "v    LN   ": (lambda: ops.gemm(EPI_VT, a_c, w["v"], vt, bc["v"], m=M, n=C, heads=heads, ntp=ntp, kp=kp, ldc=0, ln_rowstat=rowstat), C * C),
+    "N1536 bf16 NREG (what V^T would cost row-major)": (lambda: ops.gemm(EPI_BF16, a_c, w["v"], o_qk, bc["v"], m=M, n=C, ln_rowstat=rowstat, ldc=2 * C), C * C),
     "proj fp32 ": (lambda: ops.gemm(EPI_RESID, a_c, w["proj"], x32, bias["proj"], m=M, n=C, gamma=gamma), C * C),
     "proj hi/lo": (lambda: ops.gemm(EPI_RESID_HL, a_c, w["proj"], xh, bias["proj"], m=M, n=C, gamma=gamma, out2=xl, stat_part=part), C * C),
     "w12  plain": (lambda: ops.gemm(EPI_SWIGLU, a_c, w["w12"], o_hid, bias["w12"], m=M, n=2 * H), 2 * H * C),
