@@ -56,7 +56,7 @@ class VitLayer(C.Structure):
 
 class VitDesc(C.Structure):
     _fields_ = [("dim", c_int), ("depth", c_int), ("heads", c_int), ("n_reg", c_int), ("ffn_swiglu", c_int), ("hid_pad", c_int),
-                ("ln_eps", c_float), ("ln_fold", c_int), ("pe_b", c_void_p), ("reg", c_void_p), ("norm_w", c_void_p), ("norm_b", c_void_p),
+                ("ln_eps", c_float), ("qkv_merged", c_int), ("ln_fold", c_int), ("pe_b", c_void_p), ("reg", c_void_p), ("norm_w", c_void_p), ("norm_b", c_void_p),
                 ("layers", C.POINTER(VitLayer))]
 
 
@@ -109,6 +109,7 @@ SIGNATURES = {
                                               c_void_p]),
     "cvx_layernorm_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_float, c_void_p]),
     "cvx_attention_bf16": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "cvx_attention_qkv_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "cvx_preprocess_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "cvx_init_tokens": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "cvx_final_norm_features": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,

@@ -30,7 +30,14 @@ __device__ __forceinline__ int pi_row(int r) { return (r & 0x13) | ((r & 4) << 1
 //          and half the L2 -> LDS bytes per query row).  Two such workgroups per CU keep four waves per SIMD, and their 2 x 48 KB of
 //          LDS have room for a THIRD tile buffer (8: two tiles of look-ahead behind a counted wait; 9: two buffers, for A/B runs) --
 //          the three-buffer form of the 4-wave kernel (variant 3) paid for its buffer with the fourth wave per SIMD.
-template <int VARIANT>
+// VROW: V is NOT pre-transposed -- it sits row-major beside Q and K in one [rows][3C] buffer (columns 2C ..), written by ONE qkv GEMM
+//       with the plain row-major epilogue (no separate V^T GEMM launch, no scattered 16-B stores of a transposed epilogue, no vt buffer).
+//       The V tile is staged exactly like the K tile ([key][64 dims], same swizzle); the A operand of O^T += V^T P^T (32 dims x 16 keys,
+//       lane (dim r, h): keys 8h .. 8h+7) is produced by two ds_read_b64_tr_b16 per MFMA: a 16-lane group reads a 4-key x 16-dim block
+//       (lane li: key li / 4, dims 4 (li % 4) ..) and receives it transposed (lane li: dim li, the 4 keys).
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef short v8s_t __attribute__((ext_vector_type(8)));
+template <int VARIANT, bool VROW = false>
 __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS) void k_attention(const uint16_t* __restrict__ qk, long ldqk,
                                                            const uint16_t* __restrict__ vt, uint16_t* __restrict__ out,
                                                            long ldo, int heads, int ntok, int ntp, int kp, int C, int nqb,
@@ -59,7 +66,8 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
     const long row0 = (long)slice * ntp;
     const uint16_t* Qp = qk + row0 * ldqk + head * 64;
     const uint16_t* Kp = Qp + C;
-    const uint16_t* Vp = vt + ((long)(slice * heads + head) * 64) * kp;
+    const uint16_t* Vp = VROW ? Kp + C : vt + ((long)(slice * heads + head) * 64) * kp;
+    const long vpitch = VROW ? ldqk : (long)kp;  // elements between consecutive rows of the V source (VROW: token rows, else V^T dim rows)
 
     const int r = lane & 31, h = lane >> 5;
     const int q0 = qb * QB + wave * 32;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
         const int c = (jj < PPT ? jj : 0) * NT + tid;  // (PPT = 1: the second entry is unused)
         const int srow = c >> 3, schunk = ((c & 7) ^ ((srow >> 1) & 7)) << 3;
         koffs[jj] = (uint32_t)(srow * ldqk + schunk) * 2u;
-        voffs[jj] = (uint32_t)(srow * kp + schunk) * 2u;
+        voffs[jj] = (uint32_t)(srow * vpitch + schunk) * 2u;
     }
     // A query block whose rows all belong to wave 0 (1029 tokens = 8 x 128 + 5: every ninth block) runs as ONE wave: waves 1-3
     // leave at once (a hardware barrier only counts the waves still alive) and wave 0 issues their DMA pieces too -- their wave
@@ -115,10 +123,10 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
         const long kv0 = (long)j * KV_TILE;
         if constexpr (PPT == 2) {
             glds16_saddr2<NT * 16>(Kp + kv0 * ldqk, koffs[0], koffs[1], kt);
-            glds16_saddr2<NT * 16>(Vp + kv0, voffs[0], voffs[1], kt + ATT_TILE_BYTES);
+            glds16_saddr2<NT * 16>(Vp + (VROW ? kv0 * ldqk : kv0), voffs[0], voffs[1], kt + ATT_TILE_BYTES);
         } else {
             glds16_saddr(Kp + kv0 * ldqk, koffs[0], kt);
-            glds16_saddr(Vp + kv0, voffs[0], kt + ATT_TILE_BYTES);
+            glds16_saddr(Vp + (VROW ? kv0 * ldqk : kv0), voffs[0], kt + ATT_TILE_BYTES);
         }
         if (lone) {
             // the pieces of the departed waves: wave w2's thread sits 8 w2 tile rows below this one, same chunk, and its swizzle
@@ -130,13 +138,13 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
 #pragma unroll 1
             for (int w2 = 1; w2 < NW; ++w2) {
                 const uint32_t fl = (w2 & 1) ? 64u : 0u;
-                const uint32_t dk = (uint32_t)(w2 * 16) * (uint32_t)ldqk, dv = (uint32_t)(w2 * 16) * (uint32_t)kp;
+                const uint32_t dk = (uint32_t)(w2 * 16) * (uint32_t)ldqk, dv = (uint32_t)(w2 * 16) * (uint32_t)vpitch;
                 if constexpr (PPT == 2) {
                     glds16_saddr2<NT * 16>(Kp + kv0 * ldqk, (k0 + dk) ^ fl, (k1 + dk) ^ fl, kt + w2 * 1024);
-                    glds16_saddr2<NT * 16>(Vp + kv0, (v0 + dv) ^ fl, (v1 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
+                    glds16_saddr2<NT * 16>(Vp + (VROW ? kv0 * ldqk : kv0), (v0 + dv) ^ fl, (v1 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
                 } else {
                     glds16_saddr(Kp + kv0 * ldqk, (k0 + dk) ^ fl, kt + w2 * 1024);
-                    glds16_saddr(Vp + kv0, (v0 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
+                    glds16_saddr(Vp + (VROW ? kv0 * ldqk : kv0), (v0 + dv) ^ fl, kt + ATT_TILE_BYTES + w2 * 1024);
                 }
             }
         }
@@ -146,6 +154,20 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
     const int krow = pi_row(r);
     const int koff = krow * 128, ksw = (krow >> 1) & 7;  // K tile: row 32t + pi(r), 16-B chunk 2*ks + h
     const int voff = r * 128, vsw = (r >> 1) & 7;        // V^T tile: row 32dt + r, chunk 4t + 2s + h
+    // VROW: byte offset inside a V tile of this lane's transposed read for dim block dt, key quad j (keys 8h + 4j .. +3 of a 16-key
+    // step; the step itself adds (32 t + 16 sk) rows = a compile-time offset): row 8h + 4j + li / 4, dims 32 dt + 16 dgrp + 4 (li % 4)
+    [[maybe_unused]] uint32_t vtr[2][2];
+    if constexpr (VROW) {
+        const int li = lane & 15, dgrp = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 8 * h + 4 * j + (li >> 2);
+                const int chunk = (4 * dt + 2 * dgrp + ((li & 3) >> 1)) ^ ((row >> 1) & 7);
+                vtr[dt][j] = (uint32_t)(row * 128 + (chunk << 4) + (li & 1) * 8);
+            }
+    }
 
     f32x16 o[2];
 #pragma unroll
@@ -340,7 +362,16 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
                 for (int e = 0; e < 8; ++e) pf[e] = (__bf16)s[t][8 * sk + e];
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 vf = *(const bf16x8*)(vtile + dt * 4096 + voff + (((4 * t + 2 * sk + h) ^ vsw) << 4));
+                    bf16x8 vf;
+                    if constexpr (VROW) {
+                        typedef __attribute__((address_space(3))) v4s_t* lds_v4;
+                        const char* vb = vtile + (32 * t + 16 * sk) * 128;
+                        const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(vb + vtr[dt][0]));
+                        const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(vb + vtr[dt][1]));
+                        vf = __builtin_bit_cast(bf16x8, v8s_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+                    } else {
+                        vf = *(const bf16x8*)(vtile + dt * 4096 + voff + (((4 * t + 2 * sk + h) ^ vsw) << 4));
+                    }
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
             }
@@ -542,6 +573,21 @@ std::atomic<int> g_attn_variant{7};     // cvx_set_option("attn_variant"); 7 = m
 std::atomic<int> g_attn_xcd_remap{1};   // cvx_set_option("attn_xcd_remap")
 std::atomic<int> g_attn_mfma_prio{2};   // cvx_set_option("attn_mfma_prio"): s_setprio 1 around the wave's MFMA blocks (bit 0: S^T, bit 1: O^T).  Measured per layer:
                                         // 0: 1.028 ms, 1: 1.018, 2: 0.999 (default), 3: 1.003 -- the O^T MFMAs wait behind other waves' softmax VALU otherwise
+
+extern "C" int cvx_attention_qkv_bf16(const void* qkv, long ld, void* out, long ldo, int slices, int heads, int ntok, int ntp,
+                                      hipStream_t st) {
+    if (slices <= 0) return 0;
+    if (!qkv || !out) return cvx_fail("attention_qkv: null pointer");
+    if (ntp % 8 || ntp < ntok || ld % 64 || ld < 3L * heads * 64 || ldo % 4)
+        return cvx_fail("attention_qkv: need ntp%8==0, ntp>=ntok, ld%64==0 (the default kernel's lone-wave DMA offsets), ld >= 3*heads*64");
+    const int nqb = (ntok + 127) / 128;
+    const long nblk = (long)nqb * heads * slices;
+    if (nblk > 0x7fffffff) return cvx_fail("attention_qkv: grid too large");
+    const int xcd_remap = (((long)heads * slices) % 8 == 0 && g_attn_xcd_remap ? 1 : 0) | ((g_attn_mfma_prio.load() & 3) << 1);
+    hipLaunchKernelGGL((k_attention<7, true>), dim3((unsigned)nblk), dim3(ATT_THREADS), 0, st, (const uint16_t*)qkv, ld, (const uint16_t*)nullptr,
+                       (uint16_t*)out, ldo, heads, ntok, ntp, /*kp (unused)*/ 0, heads * 64, nqb, xcd_remap);
+    return cvx_check_launch();
+}
 
 extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
                                   int ntok, int ntp, int kp, hipStream_t st) {

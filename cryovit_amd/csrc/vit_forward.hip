@@ -38,6 +38,13 @@ static int vit_blocks_folded(const cvx_vit_desc* v, const cvx_vit_ws* ws, int b,
     };
     for (int i = 0; i < v->depth; ++i) {
         const cvx_vit_layer* L = &v->layers[i];
+        if (v->qkv_merged) {  // ONE pass over hi for Q, K and V; attention reads V row-major from the same buffer
+            const long c3 = rup(3L * C, 128);
+            cvx_gemm_desc d = gemm_base(CVX_EPI_BF16, ws->xh, C, L->qk_w, C, M, 3L * C, c3, C, ws->qk, 3L * C, L->qk_b);
+            d.ln_rowstat = ws->rowstat;
+            CVX_TRY(cvx_gemm_bf16(&d, st));
+            CVX_TRY(cvx_attention_qkv_bf16(ws->qk, 3L * C, ws->ao, C, b, v->heads, nt, ntp, st));
+        } else {
         {
             cvx_gemm_desc d = gemm_base(CVX_EPI_BF16, ws->xh, C, L->qk_w, C, M, 2L * C, c2, C, ws->qk, 2L * C, L->qk_b);
             d.ln_rowstat = ws->rowstat;
@@ -49,6 +56,7 @@ static int vit_blocks_folded(const cvx_vit_desc* v, const cvx_vit_ws* ws, int b,
             CVX_TRY(cvx_gemm_bf16(&d, st));
         }
         CVX_TRY(cvx_attention_bf16(ws->qk, 2L * C, ws->vt, ws->ao, C, b, v->heads, nt, ntp, kp, st));
+        }
         CVX_TRY(resid(ws->ao, C, L->proj_w, C, L->proj_b, L->ls1));
         CVX_TRY(cvx_rowstat_finalize(ws->stat_part, C / 64, rows, ws->rowstat, M, C, v->ln_eps, st));
         {

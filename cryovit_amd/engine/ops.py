@@ -153,6 +153,14 @@ def attention(qk: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, *, slices: 
          out.stride(0), slices, heads, ntok, ntp, kp)
 
 
+def attention_qkv(qkv: torch.Tensor, out: torch.Tensor, *, slices: int, heads: int, ntok: int, ntp: int) -> None:
+    """Attention over one [rows, >= 3C] bf16 buffer holding Q (log2 units) | K | V row-major (the output of one qkv GEMM)."""
+    dev = _dev_check(qkv, out)
+    assert qkv.dtype == out.dtype == torch.bfloat16 and qkv.shape[1] >= 3 * heads * 64 and qkv.shape[0] >= slices * ntp + 64
+    call(dev, "cvx_attention_qkv_bf16", _lib.load().cvx_attention_qkv_bf16, qkv.data_ptr(), qkv.stride(0), out.data_ptr(), out.stride(0), slices,
+         heads, ntok, ntp)
+
+
 def preprocess_patches(slices: torch.Tensor, out: torch.Tensor) -> None:
     dev = _dev_check(slices, out)
     assert slices.dim() == 3 and slices.is_contiguous() and slices.dtype in (torch.uint8, torch.float32)

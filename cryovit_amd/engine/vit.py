@@ -121,12 +121,15 @@ def interpolate_pos_embed(cfg: VitConfig, pos_embed: torch.Tensor, hp: int, wp: 
 class VitEngine:
     """Holds packed device weights and per-shape workspaces; ``features()`` runs one slice batch."""
 
-    def __init__(self, cfg: VitConfig, state_dict: dict, device="cuda:0", fold_ln: bool = True):
+    def __init__(self, cfg: VitConfig, state_dict: dict, device="cuda:0", fold_ln: bool = True, merge_qkv: bool | None = None):
         if not torch.cuda.is_available():
             raise ops._lib.CvxError("VitEngine needs a HIP device (no CPU fallback)")
         ops._lib.load()
         self.cfg, self.device = cfg, ops.norm_device(device)
         self.fold_ln = bool(fold_ln)  # False: the round-2 plan (fp32 stream + LayerNorm launches), kept for A/B runs
+        # one qkv GEMM (V row-major beside Q and K, transposed by the attention kernel's LDS reads) instead of a qk GEMM + a V^T GEMM;
+        # needs the folded path and a row pitch of 3C that is a multiple of 64 elements
+        self.merge_qkv = self.fold_ln and (3 * cfg.dim) % 64 == 0 if merge_qkv is None else bool(merge_qkv and self.fold_ln)
         self._pos_src = state_dict["pos_embed"].detach().float().cpu()
         self._cls = state_dict["cls_token"].detach().float().cpu().reshape(-1)
         self._ws = {}
@@ -179,8 +182,12 @@ class VitEngine:
             qkv_w[:C] *= scale
             qkv_b[:C] *= scale
             g1, b1, g2, b2 = g(p + "norm1.weight"), g(p + "norm1.bias"), g(p + "norm2.weight"), g(p + "norm2.bias")
-            qk_w, qk_b = ln_linear(qkv_w[: 2 * C], qkv_b[: 2 * C], g1, b1, round_up(2 * C, 128))
-            v_w, v_b = ln_linear(qkv_w[2 * C :], qkv_b[2 * C :], g1, b1, n128)
+            if self.merge_qkv:
+                qk_w, qk_b = ln_linear(qkv_w, qkv_b, g1, b1, round_up(3 * C, 128))  # all 3C rows: q (scaled) | k | v
+                v_w, v_b = qk_w[:0], qk_b[..., :0]  # (not read)
+            else:
+                qk_w, qk_b = ln_linear(qkv_w[: 2 * C], qkv_b[: 2 * C], g1, b1, round_up(2 * C, 128))
+                v_w, v_b = ln_linear(qkv_w[2 * C :], qkv_b[2 * C :], g1, b1, n128)
             blk = {
                 "ln1_w": up(g1), "ln1_b": up(b1),
                 "qk_w": up(qk_w), "qk_b": up(qk_b),
@@ -253,8 +260,8 @@ class VitEngine:
         z = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
         ws = {
             "ape": z(alloc_rows(b * hp * wp), 640),
-            "qk": z(rows, 2 * C),
-            "vt": z(b, cfg.heads, 64, kp),
+            "qk": z(rows, 3 * C if self.merge_qkv else 2 * C),
+            "vt": z(b, cfg.heads, 64, kp) if not self.merge_qkv else z(8),
             "ao": z(rows, C),
             "hid": z(rows, self.hid_pad),
         }
@@ -312,6 +319,7 @@ class VitEngine:
                     setattr(layers[i], name, blk[name].data_ptr())
             d = VitDesc(dim=self.cfg.dim, depth=self.cfg.depth, heads=self.cfg.heads, n_reg=self.cfg.n_reg,
                         ffn_swiglu=int(self.cfg.ffn == "swiglu"), hid_pad=self.hid_pad, ln_eps=self.cfg.ln_eps, ln_fold=int(self.fold_ln),
+                        qkv_merged=int(self.merge_qkv),
                         pe_b=self.w["pe_b"].data_ptr(), reg=self.w["reg"].data_ptr(), norm_w=self.w["norm_w"].data_ptr(),
                         norm_b=self.w["norm_b"].data_ptr(), layers=layers)
             self._cdesc = (d, layers)
@@ -350,9 +358,13 @@ class VitEngine:
             rs = ws["rowstat"]
             ops.split_stream(ws["x"], ws["xh"], ws["xl"], rs, rows=M, Cdim=C, eps=cfg.ln_eps)
             for i, blk in enumerate(self.blocks):
-                ops.gemm(EPI_BF16, ws["xh"], blk["qk_w"], ws["qk"], blk["qk_b"], m=M, n=2 * C, ln_rowstat=rs)
-                ops.gemm(EPI_VT, ws["xh"], blk["v_w"], ws["vt"], blk["v_b"], m=M, n=C, heads=cfg.heads, ntp=ntp, kp=kp, ldc=0, ln_rowstat=rs)
-                ops.attention(ws["qk"], ws["vt"], ws["ao"], slices=b, heads=cfg.heads, ntok=nt, ntp=ntp, kp=kp)
+                if self.merge_qkv:
+                    ops.gemm(EPI_BF16, ws["xh"], blk["qk_w"], ws["qk"], blk["qk_b"], m=M, n=3 * C, ln_rowstat=rs)
+                    ops.attention_qkv(ws["qk"], ws["ao"], slices=b, heads=cfg.heads, ntok=nt, ntp=ntp)
+                else:
+                    ops.gemm(EPI_BF16, ws["xh"], blk["qk_w"], ws["qk"], blk["qk_b"], m=M, n=2 * C, ln_rowstat=rs)
+                    ops.gemm(EPI_VT, ws["xh"], blk["v_w"], ws["vt"], blk["v_b"], m=M, n=C, heads=cfg.heads, ntp=ntp, kp=kp, ldc=0, ln_rowstat=rs)
+                    ops.attention(ws["qk"], ws["vt"], ws["ao"], slices=b, heads=cfg.heads, ntok=nt, ntp=ntp, kp=kp)
                 ops.gemm(EPI_RESID_HL, ws["ao"], blk["proj_w"], ws["xh"], blk["proj_b"], m=M, n=C, gamma=blk["ls1"], out2=ws["xl"],
                          stat_part=ws["part"])
                 ops.rowstat_finalize(ws["part"], rs, rows=M, Cdim=C, eps=cfg.ln_eps)

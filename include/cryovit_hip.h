@@ -144,6 +144,12 @@ int cvx_layernorm_bf16(const float* x, long ldx, const float* w, const float* b,
 int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, void* out, long ldo, int slices, int heads,
                        int ntok, int ntp, int kp, hipStream_t stream);
 
+/* The same attention reading V ROW-MAJOR from the buffer that holds Q and K: qkv bf16 [slices*ntp (+64 rows slack)][ld], columns
+ * [0,C) = Q (log2 units), [C,2C) = K, [2C,3C) = V, C = heads*64 -- the output of ONE qkv GEMM with the plain row-major epilogue
+ * (no V^T GEMM launch, no vt buffer).  ld % 64 == 0.  The kernel transposes V fragments on the LDS read (ds_read_b64_tr_b16). */
+int cvx_attention_qkv_bf16(const void* qkv, long ld, void* out, long ldo, int slices, int heads, int ntok, int ntp,
+                           hipStream_t stream);
+
 /* Pre-processing fused with im2col: raw slices [b][H][W] (u8 -> /255, or f32), edge-pad to x16, bicubic
  * x14/16 (A = -0.75, align_corners = False, clamped taps), cut into 14x14 patches of ONE channel (the 3
  * input channels are identical copies -- vit_dataset.py:117-118 -- so the patch-embed weight is summed over
@@ -310,6 +316,8 @@ typedef struct cvx_vit_layer {
 typedef struct cvx_vit_desc {
     int dim, depth, heads, n_reg, ffn_swiglu, hid_pad;
     float ln_eps;
+    int qkv_merged;                /* 1 (with ln_fold): ONE qkv GEMM per block -- layers[i].qk_w / qk_b hold all 3C rows (q | k | v), v_w / v_b
+                                      are not read, ws.qk is [rows][3C] and ws.vt is not used; attention through cvx_attention_qkv_bf16 */
     int ln_fold;                   /* 1 (the product path): LayerNorms folded into the qk / v / ffn1 GEMMs and the residual stream
                                       kept as a bf16 (hi, lo) pair.  The layers then carry qk_w / v_w / ffn1_w = bf16(W * ln_gamma)
                                       and qk_b / v_b / ffn1_b = fp32 [2][n_pad] (b' | column sums, see cvx_gemm_desc.ln_rowstat);

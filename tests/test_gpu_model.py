@@ -44,7 +44,7 @@ def _emulation(o, fold_ln):
     return o.forward_features_folded_storage if fold_ln else o.forward_features_bf16_storage
 
 
-@pytest.mark.parametrize("fold_ln", [True, False])
+@pytest.mark.parametrize("fold_ln", [True, "split_qkv", False])
 @pytest.mark.parametrize("name", ["vit_tiny_swiglu", "vit_tiny_mlp"])
 def test_vit_tiny_golden(gpu, gold, name, fold_ln):
     """Fixture tokens were produced by the oracle that is cross-checked against the HF port (make_golden.py).  Both storage plans
@@ -57,7 +57,9 @@ def test_vit_tiny_golden(gpu, gold, name, fold_ln):
     ocfg = _vit_cfgs()[name]
     sd = o.init_state_dict(ocfg, int(g["seed"]))
     assert sd_checksum(sd) == str(g["sd_sha256"]), "seeded weights differ from the ones the fixture was made with"
-    eng = VitEngine(_engine_cfg(ocfg), sd, gpu, fold_ln=fold_ln)
+    # True: the shipped plan (folded LayerNorms, ONE qkv GEMM, attention reads V row-major); "split_qkv": folded, qk + V^T GEMMs
+    eng = VitEngine(_engine_cfg(ocfg), sd, gpu, fold_ln=bool(fold_ln), merge_qkv=None if fold_ln is True else False)
+    fold_ln = bool(fold_ln)
     # the fixture input is an already-resized [b,56,84] image: feed it through the protocol entry point
     x = torch.from_numpy(g["x"])  # [2,56,84] one channel (3 identical)
     x3 = x.unsqueeze(1).expand(-1, 3, -1, -1).contiguous()

@@ -279,6 +279,39 @@ def test_attention(gpu, nt, slices, heads, attn_variant):
     assert torch.all(got[:, nt:] == 0), "padding rows must not be written"
 
 
+@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1), (133, 2, 1)])
+def test_attention_qkv_row_major_v(gpu, nt, slices, heads):
+    """cvx_attention_qkv_bf16: Q | K | V row-major in ONE buffer (the output of a single qkv GEMM); V fragments are transposed by the
+    LDS reads (ds_read_b64_tr_b16).  Same reference and tolerance as test_attention; junk in the pad rows must not leak."""
+    from cryovit_amd.engine import ops
+
+    C = heads * 64
+    ntp = ops.round_up(nt, 8)
+    M = slices * ntp
+    q, k, v = rnd(slices, nt, heads, 64, seed=24) * 1.5, rnd(slices, nt, heads, 64, seed=25), rnd(slices, nt, heads, 64, seed=26)
+    buf = torch.randn(ops.alloc_rows(M), 3 * C, generator=torch.Generator().manual_seed(27)).to(torch.bfloat16)  # junk pad rows
+    rows = buf[:M].reshape(slices, ntp, 3 * C)
+    rows[:, :nt, :C] = bf(q * 0.125 * LOG2E).reshape(slices, nt, C)
+    rows[:, :nt, C : 2 * C] = bf(k).reshape(slices, nt, C)
+    rows[:, :nt, 2 * C :] = bf(v).reshape(slices, nt, C)
+    out = torch.zeros(ops.alloc_rows(M), C, dtype=torch.bfloat16, device=gpu)
+    ops.attention_qkv(buf.to(gpu), out, slices=slices, heads=heads, ntok=nt, ntp=ntp)
+    qf, kf, vf = bf(q * 0.125 * LOG2E).float() / LOG2E, bf(k).float(), bf(v).float()
+    att = torch.softmax(torch.einsum("snhd,smhd->shnm", qf, kf), dim=-1)
+    ref = torch.einsum("shnm,smhd->snhd", att, vf).reshape(slices, nt, C)
+    got = out[:M].float().cpu().reshape(slices, ntp, C)
+    assert torch.allclose(got[:, :nt], ref, atol=2e-2, rtol=2e-2), float((got[:, :nt] - ref).abs().max())
+    assert torch.all(got[:, nt:] == 0), "padding rows must not be written"
+    # ... and the same numbers as the V^T form on the same operands (same products, same order: bit-identical)
+    kp = ops.round_up(nt, 64)
+    vt = torch.zeros(slices, heads, 64, kp, dtype=torch.bfloat16)
+    vt[..., :ntp] = rows[..., 2 * C :].reshape(slices, ntp, heads, 64).permute(0, 2, 3, 1)
+    qk2 = buf[:, : 2 * C].contiguous()
+    out2 = torch.zeros_like(out)
+    ops.attention(qk2.to(gpu), vt.to(gpu), out2, slices=slices, heads=heads, ntok=nt, ntp=ntp, kp=kp)
+    assert torch.equal(out2[:M].reshape(slices, ntp, C)[:, :nt], out[:M].reshape(slices, ntp, C)[:, :nt])
+
+
 @pytest.mark.parametrize("pad", [8, 24, 40])
 def test_attention_odd_leading_dimension(gpu, pad):
     """ldqk NOT a multiple of 64 with a single-wave last query block (ntok % 128 in (0, 32]): the default kernel's lone-wave DMA
