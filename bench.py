@@ -155,13 +155,14 @@ def stage_breakdown(vit, head, vol, labels, feats_cl, feats_f16, sb: int) -> dic
             return names[epi]
         if epi in (_lib.EPI_RESID, _lib.EPI_RESID_HL):
             return "gemm_proj" if w.shape[1] == vit.cfg.dim else "gemm_w3"
-        return "gemm_qk"
+        return "gemm_qkv" if w.shape[0] >= 3 * vit.cfg.dim else "gemm_qk"
 
     hp, wp = H_ // 16, W_ // 16
     try:
         wrap("gemm", gemm_label)
         wrap("layernorm", lambda *a, **k: "layernorm")
         wrap("attention", lambda *a, **k: "attention")
+        wrap("attention_qkv", lambda *a, **k: "attention")
         wrap("preprocess_patches", lambda *a, **k: "preprocess")
         wrap("init_tokens", lambda *a, **k: "init_tokens")
         wrap("final_norm_features", lambda *a, **k: "final_norm_features")
