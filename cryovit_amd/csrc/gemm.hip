@@ -649,9 +649,10 @@ template <class E> struct epi_can_shift<E, std::void_t<decltype(std::declval<con
 // M rows with 128x128 tiles (4x as many, quarter-size tiles: the tail costs ~0.3 of a round instead of a full one).
 static std::atomic<int> g_tail_split{2};  // 2: also for the residual epilogue with a short K loop (proj), which pays off since the tail runs on 64 x 128 tiles
 static std::atomic<int> g_tail_tile{1};  // tail launches: 1 = 64 x 128 tiles (twice the workgroups on the idle chip), 0 = 128 x 128
+static std::atomic<int> g_tail_max{128};  // (64 -> 128 in round 3: 281.26 -> 280.26 ms per tomogram; 0 = never: 282.89) largest last partial round (in 256 x 256 tiles) that is cut off into a tail launch ("gemm_tail_max")
 static long tail_split_rows(long M, long Npad, bool allow = true) {
     const long tiles_n = Npad / 256, tiles_m = (M + 255) / 256, tiles = tiles_n * tiles_m, rem = tiles % 256;
-    if (!g_tail_split || !allow || tiles < 512 || rem == 0 || rem > 64) return M;
+    if (!g_tail_split || !allow || tiles < 512 || rem == 0 || rem > g_tail_max) return M;
     const long main_mtiles = (tiles - rem) / tiles_n;
     return main_mtiles > 0 ? main_mtiles * 256 : M;
 }
@@ -793,6 +794,10 @@ extern "C" int cvx_set_option(const char* name, int value) {
     else if (!strcmp(name, "gemm_tail_split")) {
         if (!one_of({0, 1, 2})) return cvx_fail("set_option: gemm_tail_split is 0 (off), 1 (on; residual epilogues only for K >= 2048) or 2 (always)");
         g_tail_split = value;
+    }
+    else if (!strcmp(name, "gemm_tail_max")) {
+        if (value < 0 || value > 255) return cvx_fail("set_option: gemm_tail_max is a tile count in [0, 255]");
+        g_tail_max = value;
     }
     else if (!strcmp(name, "gemm_tail_tile")) {
         if (!one_of({0, 1, 2})) return cvx_fail("set_option: gemm_tail_tile is 0 (128 x 128), 1 (64 x 128) or 2 (64 x 64 tiles)");

@@ -17,7 +17,10 @@ from cryovit_amd.engine.vit import VIT_CONFIGS, VitEngine, random_state_dict  # 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--plans", default="merged,split,r2")
+ap.add_argument("--opts", default="", help="comma list of option sets NAME=VALUE[+NAME=VALUE]: each plan is timed under each set")
 args = ap.parse_args()
+from cryovit_amd import _lib  # noqa: E402
+
 dev = torch.device("cuda:0")
 cfg = VIT_CONFIGS["dinov2_vitg14_reg"]
 sd = random_state_dict(cfg, seed=2, device=dev)
@@ -26,9 +29,14 @@ plans = args.plans.split(",")
 D, H, W = 128, 512, 512
 vol = (torch.rand(D, H, W, generator=torch.Generator().manual_seed(100)) * 255).to(torch.uint8).to(dev)
 f16 = torch.zeros(1536, D, 32, 32, dtype=torch.float16, device=dev)
-res = {p: [] for p in plans}
+optsets = [o for o in args.opts.split(",") if o] or [""]
+res = {(p, o): [] for p in plans for o in optsets}
 engines = {}
 for r in range(args.rounds):
+  for o in optsets:
+    for kv in (o.split("+") if o else []):
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     for p in plans:
         if p not in engines:  # one engine alive at a time would re-pack weights every round: keep all (3 x 2.3 GB)
             engines[p] = VitEngine(cfg, sd, dev, **kw[p])
@@ -41,7 +49,7 @@ for r in range(args.rounds):
             eng.features(vol, feats_f16=f16, d_total=D, d0=0)
         e1.record()
         torch.cuda.synchronize()
-        res[p].append(e0.elapsed_time(e1) / 2)
-for p in plans:
-    ts = sorted(res[p])
-    print(f"{p:7s}: {ts[len(ts) // 2]:8.2f} ms per tomogram (ViT-g features alone; min {ts[0]:.2f}, max {ts[-1]:.2f})")
+        res[(p, o)].append(e0.elapsed_time(e1) / 2)
+for (p, o), ts in res.items():
+    ts = sorted(ts)
+    print(f"{p:7s} {o:28s}: {ts[len(ts) // 2]:8.2f} ms per tomogram (ViT-g features alone; min {ts[0]:.2f}, max {ts[-1]:.2f})")
