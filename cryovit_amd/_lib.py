@@ -118,6 +118,7 @@ SIGNATURES = {
                                            c_int, c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p]),
     "cvx_split_stream": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p]),
     "cvx_rowstat_finalize": (c_int, [c_void_p, c_int, c_long, c_void_p, c_long, c_int, c_float, c_void_p]),
+    "cvx_merge_stream": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_void_p]),
     "cvx_im2col_patches": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "cvx_features_to_channels_last": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p]),
     "cvx_groupnorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),

@@ -258,10 +258,10 @@ struct EpiResidHL {
     template <int NV>
     __device__ __forceinline__ void store(const Ctx<NV>& c, long n0, long m, const float* acc) const {
         static_assert(NV == 16, "hi/lo residual epilogue: 16 contiguous columns per lane (64-column slots)");
-        const bool ok = m < m_valid;
+        const bool ok = m < m_valid && n0 < n_valid;  // (n_valid % 64 == 0: the four lane groups of a slot agree)
         const long mm = ok ? m : 0;
-        const uint16_t* ph = xh + mm * ldx + n0;
-        const uint16_t* pl = xl + mm * ldx + n0;
+        const uint16_t* ph = xh + mm * ldx + (ok ? n0 : 0);
+        const uint16_t* pl = xl + mm * ldx + (ok ? n0 : 0);
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -952,7 +952,8 @@ static int gemm_dispatch(const cvx_gemm_desc* d, hipStream_t st) {
         case CVX_EPI_RESID_HL: {
             if (!d->out || !d->out2 || !d->bias || !d->gamma || !d->stat_part)
                 return cvx_fail("gemm: the hi/lo residual epilogue needs out (hi), out2 (lo), bias, gamma and stat_part");
-            if (d->n != d->n_pad || d->n_pad % 64) return cvx_fail("gemm: the hi/lo residual epilogue needs N == n_pad, a multiple of 64");
+            if (d->n % 64 || d->n_pad % 64 || d->n > d->n_pad || d->ldc < d->n)
+                return cvx_fail("gemm: the hi/lo residual epilogue needs N a multiple of 64 (64-column statistics slots), N <= n_pad, ldc >= N");
             if (d->stat_rows < (d->m + 255) / 256 * 256) return cvx_fail("gemm: stat_rows must cover M rounded up to 256 rows");
             EpiResidHL e{(uint16_t*)d->out, (uint16_t*)d->out2, d->ldc, d->bias, d->gamma, d->stat_part, d->stat_rows, d->m, d->n};
             return dispatch_nreg(A, d->lda, W, d->ldw, d->m, d->n_pad, d->k_pad, e, st);

@@ -465,7 +465,9 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
             const long mw = l0 + wl * 128, nw = r0 + wr * 64;      // first row / column of this wave's 128 x 64 part
             const char* hw = (const char*)(epi.xh + mw * epi.ldx + nw);   // wave-uniform
             const char* lw = (const char*)(epi.xl + mw * epi.ldx + nw);
-            const long mleft = epi.m_valid - mw;                   // rows of the part inside the problem (columns: always all)
+            const long mleft = epi.m_valid - mw;                   // rows of the part inside the problem
+            // columns: n_valid is a multiple of 64, so a wave's 64 columns are inside the problem or outside it as a whole (wave-uniform)
+            const bool nok = FULL || nw + 64 <= epi.n_valid;
             uint32_t loff[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) loff[j] = ((uint32_t)(r8 + 8 * j) * ldx + (uint32_t)c8) * 2u;  // BYTES
@@ -474,7 +476,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                 const long ub = (long)(16 * u) * ldx * 2;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const bool ok = FULL || 16 * u + 8 * j + r8 < mleft;
+                    const bool ok = FULL || (nok && 16 * u + 8 * j + r8 < mleft);
                     dst[2 * j] = ok ? __builtin_nontemporal_load((const u32x4*)(hw + ub + loff[j])) : u32x4{0u, 0u, 0u, 0u};
                     dst[2 * j + 1] = ok ? __builtin_nontemporal_load((const u32x4*)(lw + ub + loff[j])) : u32x4{0u, 0u, 0u, 0u};
                 }
@@ -525,14 +527,14 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
                     rs += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rs), 0x141, 0xF, 0xF, true));
                     rq += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, rq), 0x141, 0xF, 0xF, true));
                     if ((lane & 7) == 0) *(float2*)(cbuf + (16 * u + 8 * j + r8) * 8) = float2{rs, rq};
-                    if (FULL || 16 * u + 8 * j + r8 < mleft) {
+                    if (FULL || (nok && 16 * u + 8 * j + r8 < mleft)) {
                         gst16_saddr((void*)(hw + ub), loff[j], nh);        // the next GEMM reads hi: plain policy
                         gst16_saddr_nt((void*)(lw + ub), loff[j], nl);     // lo is read once, a whole layer later: streaming
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            {
+            if (FULL || nok) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const f32x4 st4 = *(const f32x4*)(cbuf + lane * 16);  // rows 2 lane, 2 lane + 1 of the wave's 128
                 const uintptr_t pp = (uintptr_t)(epi.part + (((r0 >> 6) + wr) * epi.part_rows + mw) * 2);  // (wave-uniform: into SGPRs)

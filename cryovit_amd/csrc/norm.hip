@@ -506,6 +506,20 @@ __global__ __launch_bounds__(256) void k_split_stream(const float* __restrict__ 
     if (lane == 0) *(float2*)(rowstat + 2 * row) = float2{rstd, -mean * rstd};
 }
 
+// (hi, lo) -> fp32 rows (x = hi + lo, exact): where a folded stretch of the stream hands over to kernels that take fp32 (Hiera's
+// stage transitions)
+__global__ __launch_bounds__(256) void k_merge_stream(const uint16_t* __restrict__ xh, const uint16_t* __restrict__ xl, long ld, float* __restrict__ x,
+                                                      long ldx, long rows, int C8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C8) return;
+    const long row = idx / C8;
+    const int c = (int)(idx - row * C8) * 8;
+    const uint4 a = *(const uint4*)(xh + row * ld + c), b = *(const uint4*)(xl + row * ld + c);
+    float* o = x + row * ldx + c;
+    *(float4*)o = float4{bflo(a.x) + bflo(b.x), bfhi(a.x) + bfhi(b.x), bflo(a.y) + bflo(b.y), bfhi(a.y) + bfhi(b.y)};
+    *(float4*)(o + 4) = float4{bflo(a.z) + bflo(b.z), bfhi(a.z) + bfhi(b.z), bflo(a.w) + bflo(b.w), bfhi(a.w) + bfhi(b.w)};
+}
+
 // part[slot][part_rows][2] (sum, sum of squares of a row over 64 columns, written by the hi/lo residual epilogue) ->
 // rowstat[row] = (rstd, -mean * rstd).  Fixed order, double accumulation: 24 partials of fp32 sums lose nothing further.
 __global__ __launch_bounds__(64) void k_rowstat_finalize(const float* __restrict__ part, int nslot, long part_rows, float* __restrict__ rowstat,
@@ -602,6 +616,16 @@ extern "C" int cvx_split_stream(const float* x, long ldx, void* xh, void* xl, lo
     if (C % 8 || C > 64 * 8 * LN_MAXJ8 || ldx % 4 || ld % 8) return cvx_fail("split_stream: C%8==0, C<=2048, ldx%4==0, ld%8==0 required");
     hipLaunchKernelGGL(k_split_stream, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ldx, (uint16_t*)xh, (uint16_t*)xl, ld, rowstat, rows,
                        C, eps);
+    return cvx_check_launch();
+}
+
+extern "C" int cvx_merge_stream(const void* xh, const void* xl, long ld, float* x, long ldx, long rows, int C, hipStream_t st) {
+    if (rows <= 0) return 0;
+    if (!xh || !xl || !x) return cvx_fail("merge_stream: null pointer");
+    if (C % 8 || ld % 8 || ldx % 4) return cvx_fail("merge_stream: C%8==0, ld%8==0, ldx%4==0 required");
+    const long total = rows * (C / 8);
+    hipLaunchKernelGGL(k_merge_stream, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint16_t*)xh, (const uint16_t*)xl, ld, x, ldx,
+                       rows, C / 8);
     return cvx_check_launch();
 }
 

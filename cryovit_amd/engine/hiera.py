@@ -27,7 +27,7 @@ from dataclasses import dataclass
 import torch
 import torch.nn.functional as F
 
-from cryovit_amd._lib import EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_PATCH, EPI_RESID
+from cryovit_amd._lib import EPI_RESID_HL, EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_PATCH, EPI_RESID
 from cryovit_amd.engine import ops
 from cryovit_amd.engine.ops import alloc_rows, round_up
 
@@ -138,11 +138,15 @@ def _npad(n: int, k: int = 0) -> int:
 class HieraEngine:
     """Packed device weights + per-batch workspaces; ``encode()`` runs one batch of slices."""
 
-    def __init__(self, cfg: HieraConfig, state_dict: dict, device="cuda:0"):
+    def __init__(self, cfg: HieraConfig, state_dict: dict, device="cuda:0", fold_ln: bool = True):
         if not torch.cuda.is_available():
             raise ops._lib.CvxError("HieraEngine needs a HIP device (no CPU fallback)")
         ops._lib.load()
         self.cfg, self.device = cfg, ops.norm_device(device)
+        # round 3: in the stages whose width is a multiple of 64 (Hiera-L: stages 3 and 4, 40 of its 48 blocks) the residual stream is
+        # kept as a bf16 (hi, lo) pair and the LayerNorms are folded into the qkv / fc1 GEMMs, exactly as in the ViT path
+        # (engine/vit.py, DESIGN.md s.4); stage transitions and the narrow stages run the round-2 plan (fp32 stream + LayerNorm kernels)
+        self.fold_ln = bool(fold_ln)
         S = cfg.image_size
         self.grids = tuple(S // 4 // 2**i for i in range(len(cfg.stages)))
         self.plan, self.stage_ends = cfg.block_plan()
@@ -178,6 +182,18 @@ class HieraEngine:
             bp[: b.numel()] = b.to(dev)
             return wp, bp
 
+        def ln_lin(wk, bk, gk, betak):
+            """A linear layer behind LayerNorm(gamma, beta), folded: W' = bf16(W * gamma), bias table [2, n_pad] = b + W beta | column
+            sums of W' (engine/vit.py::_pack)."""
+            w, b, gamma, beta = g(wk), g(bk), g(gk), g(betak)
+            n_pad, k_pad = _npad(w.shape[0], w.shape[1]), round_up(w.shape[1], 64)
+            wp = torch.zeros(n_pad, k_pad, dtype=torch.bfloat16, device=dev)
+            wp[: w.shape[0], : w.shape[1]] = (w * gamma[None, :]).to(dev).to(torch.bfloat16)
+            bc = torch.zeros(2, n_pad, dtype=torch.float32, device=dev)
+            bc[0, : w.shape[0]] = (b.double() + w.double() @ beta.double()).float().to(dev)
+            bc[1] = wp.double().sum(dim=1).float()
+            return wp, bc
+
         E, G0 = cfg.embed_dim, self.grids[0]
         self.pe_w, self.pe_b = lin("trunk.patch_embed.proj.weight", "trunk.patch_embed.proj.bias")  # K = c*49 + ky*7 + kx
         # position table: bicubic(pos_embed) + tiled window embedding (hieradet.py _get_pos_embed); weight-only, once.
@@ -197,6 +213,10 @@ class HieraEngine:
                    "fc2": lin(p + "mlp.layers.1.weight", p + "mlp.layers.1.bias")}
             if dim != dout:
                 blk["short"] = lin(p + "proj.weight", p + "proj.bias")
+            if self.fold_ln and dout % 64 == 0:  # second half of the block (norm2 -> fc1) on the folded stream
+                blk["fc1_ln"] = ln_lin(p + "mlp.layers.0.weight", p + "mlp.layers.0.bias", p + "norm2.weight", p + "norm2.bias")
+                if dim == dout:                  # ... and the first half (norm1 -> qkv) unless this is a stage transition
+                    blk["qkv_ln"] = ln_lin(p + "attn.qkv.weight", p + "attn.qkv.bias", p + "norm1.weight", p + "norm1.bias")
             self.blocks.append(blk)
         n = len(cfg.stages) - 1
         self.neck = [lin(f"neck.convs.{n - s}.conv.weight", f"neck.convs.{n - s}.conv.bias") for s in range(n + 1)]  # by stage
@@ -207,6 +227,13 @@ class HieraEngine:
         key = (name, rows, cols, dtype)
         if key not in self._ws:
             self._ws[key] = torch.zeros(alloc_rows(rows), cols, dtype=dtype, device=self.device)
+        return self._ws[key]
+
+    def _part(self, stage: int, rows: int, dout: int) -> torch.Tensor:
+        """fp32 [dout / 64, alloc_rows(rows), 2]: the 64-column partial row sums a hi/lo residual GEMM leaves for cvx_rowstat_finalize."""
+        key = ("part", stage, rows, dout)
+        if key not in self._ws:
+            self._ws[key] = torch.zeros(dout // 64, alloc_rows(rows), 2, dtype=torch.float32, device=self.device)
         return self._ws[key]
 
     def pos_enc(self, level: int) -> torch.Tensor:
@@ -231,10 +258,33 @@ class HieraEngine:
         x = self._buf("x0", rows, cfg.embed_dim, f32)
         ops.gemm(EPI_PATCH, patches, self.pe_w, x, self.pe_b, m=rows, n=cfg.embed_dim, pos=self.pos, npatch=G * G, ntp=G * G, tok0=0)
         stage, stage_out = 0, []
+        folded = None  # (xh, xl, part, rowstat) while the stream of the current stage lives as a bf16 pair
         for i, (dim, dout, heads, window, q_stride) in enumerate(self.plan):
             blk = self.blocks[i]
             hd = dout // heads
             w = window or G
+            if folded is not None and "qkv_ln" in blk:
+                # ---- a whole block on the folded stream: no LayerNorm kernel, no fp32 x ----
+                xh, xl, part, rs = folded
+                qkv = self._buf(f"qkv{stage}", rows, 3 * dout, bf)
+                ops.gemm(EPI_BF16, xh, blk["qkv_ln"][0], qkv, blk["qkv_ln"][1], m=rows, n=3 * dout, ln_rowstat=rs)
+                ao = self._buf(f"ao{stage}", rows, round_up(dout, 64), bf)
+                ops.window_attention(qkv, 0, qkv, dout, 2 * dout, ao, slices=b, heads=heads, head_dim=hd, grid=G, window=w, q_grid=G,
+                                     q_window=w)
+                ops.gemm(EPI_RESID_HL, ao, blk["proj"][0], xh, blk["proj"][1], gamma=self.ones, m=rows, n=dout, out2=xl, stat_part=part)
+                ops.rowstat_finalize(part, rs, rows=rows, Cdim=dout, eps=1e-6)
+                hid = self._buf(f"hid{stage}", rows, round_up(4 * dout, 64), bf)
+                ops.gemm(EPI_BF16_GELU, xh, blk["fc1_ln"][0], hid, blk["fc1_ln"][1], m=rows, n=4 * dout, ln_rowstat=rs)
+                ops.gemm(EPI_RESID_HL, hid, blk["fc2"][0], xh, blk["fc2"][1], gamma=self.ones, m=rows, n=dout, out2=xl, stat_part=part)
+                ops.rowstat_finalize(part, rs, rows=rows, Cdim=dout, eps=1e-6)
+                if i in self.stage_ends:
+                    stage_out.append((None, G, rows, dout, xh))  # the neck reads bf16(x) = hi
+                continue
+            if folded is not None:  # a stage transition behind a folded stage: back to fp32 for the round-2 first half
+                xh, xl, _, _ = folded
+                x = self._buf(f"x{stage}", rows, dim, f32)
+                ops.merge_stream(xh, xl, x, rows=rows, Cdim=dim)
+                folded = None
             xn = self._buf(f"xn{stage}", rows, round_up(dim, 64), bf)
             ops.layernorm(x, *blk["n1"], xn, rows, dim, 1e-6)
             if dim != dout:  # stage transition: new width on the old grid, then pool queries and shortcut
@@ -266,27 +316,44 @@ class HieraEngine:
                 ops.window_attention(qkv, 0, qkv, dout, 2 * dout, ao, slices=b, heads=heads, head_dim=hd, grid=G, window=w, q_grid=G,
                                      q_window=w)
             ops.gemm(EPI_RESID, ao, blk["proj"][0], x, blk["proj"][1], gamma=self.ones, m=rows, n=dout)
+            hid = self._buf(f"hid{stage}", rows, round_up(4 * dout, 64), bf)
+            if "fc1_ln" in blk:
+                # from here the stage's stream is a bf16 pair: split x (and take the row constants of norm2 from it), then the second
+                # half of this block in the folded form
+                xh, xl = self._buf(f"xh{stage}", rows, dout, bf), self._buf(f"xl{stage}", rows, dout, bf)
+                part = self._part(stage, rows, dout)
+                rs = self._buf(f"rowstat{stage}", rows, 2, f32)
+                ops.split_stream(x, xh, xl, rs, rows=rows, Cdim=dout, eps=1e-6)
+                ops.gemm(EPI_BF16_GELU, xh, blk["fc1_ln"][0], hid, blk["fc1_ln"][1], m=rows, n=4 * dout, ln_rowstat=rs)
+                ops.gemm(EPI_RESID_HL, hid, blk["fc2"][0], xh, blk["fc2"][1], gamma=self.ones, m=rows, n=dout, out2=xl, stat_part=part)
+                ops.rowstat_finalize(part, rs, rows=rows, Cdim=dout, eps=1e-6)
+                folded = (xh, xl, part, rs)
+                if i in self.stage_ends:
+                    stage_out.append((None, G, rows, dout, xh))
+                continue
             xn2 = self._buf(f"xn{stage}", rows, round_up(dout, 64), bf)
             ops.layernorm(x, *blk["n2"], xn2, rows, dout, 1e-6)
-            hid = self._buf(f"hid{stage}", rows, round_up(4 * dout, 64), bf)
             ops.gemm(EPI_BF16_GELU, xn2, blk["fc1"][0], hid, blk["fc1"][1], m=rows, n=4 * dout)
             ops.gemm(EPI_RESID, hid, blk["fc2"][0], x, blk["fc2"][1], gamma=self.ones, m=rows, n=dout)
             if i in self.stage_ends:
-                stage_out.append((x, G, rows, dout))
+                stage_out.append((x, G, rows, dout, None))
         # FPN neck: lateral 1x1 convs in fp32, top-down nearest upsampling for the listed levels, float16 [b,256,g,g] out
         n = len(stage_out) - 1
         lats = []
-        for s, (xs, g, r, c) in enumerate(stage_out):
+        for s, (xs, g, r, c, xhi) in enumerate(stage_out):
             if s > n - cfg.scalp and not (s == n and (n - 1) in cfg.fpn_top_down_levels):
                 lats.append(None)  # dropped by scalp and not needed by a finer level
                 continue
-            xb = self._buf(f"neck_in{s}", r, round_up(c, 64), bf)
-            ops.cast_bf16(xs, xb, rows=r, C=c)
+            if xhi is not None:
+                xb = xhi  # a folded stage ends as a bf16 pair: its hi half IS bf16(x), the lateral conv's operand
+            else:
+                xb = self._buf(f"neck_in{s}", r, round_up(c, 64), bf)
+                ops.cast_bf16(xs, xb, rows=r, C=c)
             lat = self._buf(f"lat{s}", r, cfg.d_model, f32)
             ops.gemm(EPI_F32, xb, self.neck[s][0], lat, self.neck[s][1], gamma=self.ones, m=r, n=cfg.d_model)
             lats.append(lat)
         for s in range(n + 1 - cfg.scalp):
-            _, g, _, _ = stage_out[s]
+            _, g, _, _, _ = stage_out[s]
             coarse = lats[s + 1] if (s in cfg.fpn_top_down_levels and s < n) else None
             ops.fpn_level_out(lats[s], coarse, outs[s][d0 : d0 + b], slices=b, C=cfg.d_model, grid=g)
 

@@ -84,7 +84,7 @@ def gemm(epilogue: int, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bia
     if epilogue == _lib.EPI_RESID_HL:
         if out2 is None or stat_part is None or out.dtype != torch.bfloat16 or out2.dtype != torch.bfloat16 or stat_part.dim() != 3:
             raise _lib.CvxError("gemm: EPI_RESID_HL needs bf16 out / out2 and stat_part fp32 [n_pad/64, rows, 2]")
-        if stat_part.shape[0] * 64 < w.shape[0] or stat_part.shape[1] < round_up(m, 256) or out2.stride(0) != out.stride(0):
+        if stat_part.shape[0] * 64 < n or stat_part.shape[1] < round_up(m, 256) or out2.stride(0) != out.stride(0):
             raise _lib.CvxError("gemm: stat_part too small or hi / lo leading dimensions differ")
     d = GemmDesc()
     d.epilogue = epilogue
@@ -198,6 +198,13 @@ def split_stream(x: torch.Tensor, xh: torch.Tensor, xl: torch.Tensor, rowstat: t
     assert xh.stride(0) == xl.stride(0) and min(x.shape[0], xh.shape[0], xl.shape[0]) >= rows and rowstat.numel() >= 2 * rows
     call(dev, "cvx_split_stream", _lib.load().cvx_split_stream, x.data_ptr(), x.stride(0), xh.data_ptr(), xl.data_ptr(), xh.stride(0),
          rowstat.data_ptr(), rows, Cdim, eps)
+
+
+def merge_stream(xh: torch.Tensor, xl: torch.Tensor, x: torch.Tensor, *, rows: int, Cdim: int) -> None:
+    """bf16 (hi, lo) pair -> fp32 rows x = hi + lo."""
+    dev = _dev_check(xh, xl, x)
+    assert xh.dtype == xl.dtype == torch.bfloat16 and x.dtype == torch.float32 and xh.stride(0) == xl.stride(0)
+    call(dev, "cvx_merge_stream", _lib.load().cvx_merge_stream, xh.data_ptr(), xl.data_ptr(), xh.stride(0), x.data_ptr(), x.stride(0), rows, Cdim)
 
 
 def rowstat_finalize(stat_part: torch.Tensor, rowstat: torch.Tensor, *, rows: int, Cdim: int, eps: float) -> None:

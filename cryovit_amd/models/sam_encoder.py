@@ -23,11 +23,11 @@ MODEL_NAMES = {"SAM2": "sam2.1_hiera_l"}  # configs/model/sam2.yaml `name` -> en
 
 
 class SamImageEncoder:
-    def __init__(self, name: str, state_dict: dict, device="cuda:0", slice_batch: int = 64):
+    def __init__(self, name: str, state_dict: dict, device="cuda:0", slice_batch: int = 64, fold_ln: bool = True):
         if name not in HIERA_CONFIGS:
             raise ValueError(f"unknown SAM2 encoder {name!r}; known: {sorted(HIERA_CONFIGS)}")
         self.name, self.cfg = name, HIERA_CONFIGS[name]
-        self.engine = HieraEngine(self.cfg, state_dict, device)
+        self.engine = HieraEngine(self.cfg, state_dict, device, fold_ln=fold_ln)
         self.device = self.engine.device
         self.image_size = self.cfg.image_size
         self.slice_batch = slice_batch
@@ -78,12 +78,12 @@ class SamImageEncoder:
 
 
 def load_sam_encoder(name: str = "sam2.1_hiera_l", model_dir=None, checkpoint=None, synthetic_seed=None, device="cuda:0",
-                     slice_batch: int = 64) -> SamImageEncoder:
+                     slice_batch: int = 64, fold_ln: bool = True) -> SamImageEncoder:
     """Weights: the upstream ``sam2.1_hiera_large.pt`` (``{"model": state_dict}``, keys ``image_encoder.*``) read with
     ``torch.load(weights_only=True)``; never downloaded.  ``synthetic_seed`` builds seeded random weights instead."""
     name = MODEL_NAMES.get(name, name)
     if synthetic_seed is not None:
-        return SamImageEncoder(name, random_state_dict(HIERA_CONFIGS[name], int(synthetic_seed), device=device), device, slice_batch)
+        return SamImageEncoder(name, random_state_dict(HIERA_CONFIGS[name], int(synthetic_seed), device=device), device, slice_batch, fold_ln)
     path = Path(checkpoint) if checkpoint else Path(model_dir) / CHECKPOINT_FILES[name]
     if not path.exists():
         raise FileNotFoundError(f"SAM2 checkpoint {path} not found. Place the upstream file there (this build never downloads), "
@@ -91,4 +91,4 @@ def load_sam_encoder(name: str = "sam2.1_hiera_l", model_dir=None, checkpoint=No
     sd = torch.load(path, map_location="cpu", weights_only=True)
     sd = sd.get("model", sd)
     sd = {k: v for k, v in sd.items() if k.startswith(("image_encoder.", "trunk.", "neck."))}
-    return SamImageEncoder(name, sd, device, slice_batch)
+    return SamImageEncoder(name, sd, device, slice_batch, fold_ln)

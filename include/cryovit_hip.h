@@ -67,7 +67,7 @@ enum cvx_epilogue {
     CVX_EPI_F32 = 7,       /* out fp32 [M][ldc]       = gamma * (acc + bias)   (written, not accumulated)  */
     CVX_EPI_RESID_HL = 8   /* the residual stream as a bf16 PAIR: x = hi + lo (out = hi, out2 = lo, both bf16 [M][ldc]);
                               x += gamma * (acc + bias); hi = bf16(x), lo = bf16(x - hi); stat_part[n / 64][m] = (sum, sum of
-                              squares) of the new x over 64-column slots (N == n_pad, a multiple of 64).  hi is the next GEMM's A
+                              squares) of the new x over 64-column slots (N a multiple of 64, N <= n_pad).  hi is the next GEMM's A
                               operand: see ln_rowstat                                                            */
 };
 
@@ -185,6 +185,8 @@ int cvx_split_stream(const float* x, long ldx, void* xh, void* xl, long ld, floa
                      hipStream_t stream);
 int cvx_rowstat_finalize(const float* part, int nslot, long part_rows, float* rowstat, long rows, int C, float eps,
                          hipStream_t stream);
+/* (hi, lo) -> fp32 rows, x = hi + lo (exact): the hand-over from a folded stretch of a stream to kernels that take fp32. */
+int cvx_merge_stream(const void* xh, const void* xl, long ld, float* x, long ldx, long rows, int C, hipStream_t stream);
 
 /* im2col of already-resized 3-channel images x fp32 [b][3][Hi][Wi] (Hi, Wi multiples of 14) for the
  * encoder-protocol entry point forward_features(x) (run/dino_features.py:58): out bf16 [b*hp*wp][k_pad],

@@ -212,6 +212,112 @@ def trunk_forward(cfg: HieraCfg, sd, img: torch.Tensor, r=_id) -> list[torch.Ten
     return outs
 
 
+def trunk_forward_folded(cfg: HieraCfg, sd, img: torch.Tensor) -> list[torch.Tensor]:
+    """``trunk_forward`` with the storage plan the HIP path ships in round 3 (exact arithmetic, ``_bf`` where it stores bf16): in the
+    stages whose width is a multiple of 64 the residual stream is a bf16 pair (hi = bf16(x), lo = bf16(x - hi)) and norm1 / norm2 are
+    FOLDED into the qkv / fc1 layers -- the GEMM's A operand is hi, its weight bf16(W * gamma), and the accumulator is normalised with
+    row statistics of the fp32 value before the split: y = rstd (hi W'^T) - mean rstd sum_k W' + (b + W beta).  A stage transition
+    (and the narrow stages) run the round-2 plan on hi + lo; the first half of a transition INTO a wide stage is un-folded, its second
+    half folded.  A folded stage hands bf16(x) = hi to the neck."""
+    r = _bf
+    x = F.conv2d(r(img), r(sd["trunk.patch_embed.proj.weight"]), sd["trunk.patch_embed.proj.bias"], stride=4, padding=3).permute(0, 2, 3, 1)
+    x = x + pos_embed(cfg, sd, x.shape[1], x.shape[2])
+    plan, stage_ends = cfg.block_plan()
+
+    def stats(v):
+        mu = v.mean(-1, keepdim=True)
+        var = ((v * v).mean(-1, keepdim=True) - mu * mu).clamp_min(0.0)
+        rstd = torch.rsqrt(var + 1e-6)
+        return rstd, -mu * rstd
+
+    def ln_linear(hi, rs, gamma, beta, wm, bias):
+        wg = r(wm * gamma[None, :])
+        return rs[0] * (hi @ wg.t()) + rs[1] * wg.sum(1) + (bias.double() + wm.double() @ beta.double()).float()
+
+    def split(v):
+        hi = r(v)
+        return hi, r(v - hi)
+
+    outs, pair = [], None  # pair = (hi, lo, row statistics) while the stage's stream is folded
+    for i, spec in enumerate(plan):
+        dim, dim_out, heads, window, q_stride = spec
+        p = f"trunk.blocks.{i}."
+        if pair is not None and dim == dim_out:
+            hi, lo, rs = pair
+            B, H, W, _ = hi.shape
+            h1 = ln_linear(hi, rs, sd[p + "norm1.weight"], sd[p + "norm1.bias"], sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+            if window > 0:
+                h1, pad_hw = window_partition(h1, window)
+            # attention on the already-computed qkv rows (the q/k/v rounding, probabilities and output as in ``attention``)
+            Bw, Hw, Ww, _ = h1.shape
+            qkv = r(h1).reshape(Bw, Hw * Ww, 3, heads, -1)
+            q, k, v = qkv.unbind(2)
+            qt, kt, vt = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+            sc = (qt @ kt.transpose(-2, -1)) * (qt.shape[-1] ** -0.5)
+            e = torch.exp(sc - sc.amax(-1, keepdim=True))
+            o = r(((r(e) @ vt) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(Bw, Hw, Ww, -1))
+            a = F.linear(o, r(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
+            if window > 0:
+                a = window_unpartition(a, window, pad_hw, (H, W))
+            t = (hi + lo) + a
+            rs = stats(t)
+            hi, lo = split(t)
+            h2 = ln_linear(hi, rs, sd[p + "norm2.weight"], sd[p + "norm2.bias"], sd[p + "mlp.layers.0.weight"], sd[p + "mlp.layers.0.bias"])
+            t = (hi + lo) + F.linear(r(F.gelu(h2)), r(sd[p + "mlp.layers.1.weight"]), sd[p + "mlp.layers.1.bias"])
+            rs = stats(t)
+            hi, lo = split(t)
+            pair = (hi, lo, rs)
+            if i in stage_ends:
+                outs.append(hi)
+            continue
+        if pair is not None:  # transition out of a folded stage: the round-2 first half on hi + lo
+            x = pair[0] + pair[1]
+            pair = None
+        if dim_out % 64 == 0:
+            # first half as in ``block_forward`` (un-folded), second half folded
+            shortcut = x
+            xn = r(F.layer_norm(x, (dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6))
+            if dim != dim_out:
+                shortcut = F.linear(xn, r(sd[p + "proj.weight"]), sd[p + "proj.bias"])
+                if q_stride:
+                    shortcut = do_pool(shortcut, q_stride)
+            ws = window
+            if window > 0:
+                H, W = xn.shape[1:3]
+                xn, pad_hw = window_partition(xn, window)
+            a = attention(sd, p + "attn.", xn, heads, q_stride, r)
+            if q_stride:
+                ws = window // q_stride
+                H, W = shortcut.shape[1:3]
+                pad_hw = (H + (-H) % ws, W + (-W) % ws) if ws > 0 else (H, W)
+            if window > 0:
+                a = window_unpartition(a, ws, pad_hw, (H, W))
+            t = shortcut + a
+            rs = stats(t)
+            hi, lo = split(t)
+            h2 = ln_linear(hi, rs, sd[p + "norm2.weight"], sd[p + "norm2.bias"], sd[p + "mlp.layers.0.weight"], sd[p + "mlp.layers.0.bias"])
+            t = (hi + lo) + F.linear(r(F.gelu(h2)), r(sd[p + "mlp.layers.1.weight"]), sd[p + "mlp.layers.1.bias"])
+            rs = stats(t)
+            hi, lo = split(t)
+            pair = (hi, lo, rs)
+            if i in stage_ends:
+                outs.append(hi)
+            continue
+        x = block_forward(sd, i, spec, x, r)
+        if i in stage_ends:
+            outs.append(x)
+    return outs
+
+
+@torch.no_grad()
+def forward_features_folded_storage(cfg: HieraCfg, sd, data: torch.Tensor) -> dict:
+    """The round-3 storage plan of the HIP Hiera path (``trunk_forward_folded``) + the neck of ``forward_features_bf16_storage``."""
+    feats, pos = neck_forward(cfg, sd, trunk_forward_folded(cfg, sd, resize_input(data.float(), cfg.image_size)), _bf)
+    if cfg.scalp > 0:
+        feats, pos = feats[: -cfg.scalp], pos[: -cfg.scalp]
+    return {"vision_features": feats[-1], "vision_pos_enc": pos, "backbone_fpn": feats}
+
+
 def sine_position_encoding(d_model: int, h: int, w: int, temperature: float = 10000.0) -> torch.Tensor:
     """[d_model,h,w] ``PositionEmbeddingSine(num_pos_feats=d_model, normalize=True)`` of the sam2 package (scale 2*pi, eps 1e-6)."""
     npf = d_model // 2

@@ -1050,6 +1050,11 @@ def test_variants_on_the_ablation_build(gpu):
     root = Path(__file__).resolve().parent.parent
     if not (root / "cryovit_amd" / "libcryovit_hip_ablation.so").exists():
         pytest.skip("libcryovit_hip_ablation.so not built (python -m cryovit_amd.build --ablation)")
+    from cryovit_amd.build import _fingerprint
+
+    stamp = root / "cryovit_amd" / "build_ablation" / "fingerprint"
+    if not stamp.exists() or stamp.read_text() != _fingerprint() + "+ablation":
+        pytest.skip("libcryovit_hip_ablation.so is older than the sources (python -m cryovit_amd.build --ablation; __graft_entry__.build() does)")
     env = dict(os.environ, CVX_ABLATION_LIB="1")
     r = subprocess.run([sys.executable, "-m", "pytest", str(Path(__file__)), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
                         "test_attention or test_gemm256 or test_conv3d"], cwd=root, env=env, capture_output=True, text=True, timeout=1500)

@@ -128,7 +128,7 @@ def test_sam_patches(gpu, H, W, dtype):
         assert torch.equal(out[: D * 256, :147].cpu(), bf(ref))  # no resize: bit-exact
 
 
-def _encoder_case(gpu, vol, cfg_name="test"):
+def _encoder_case(gpu, vol, cfg_name="test", fold_ln=True):
     from cryovit_amd.engine.hiera import HieraConfig, HieraEngine
     from oracle import sam2_hiera as oh
 
@@ -137,14 +137,15 @@ def _encoder_case(gpu, vol, cfg_name="test"):
                       image_size=ocfg.image_size)
     assert cfg.block_plan() == ocfg.block_plan()
     sd = oh.init_state_dict(ocfg, seed=3)
-    eng = HieraEngine(cfg, {"image_encoder." + k: v for k, v in sd.items()}, gpu)  # checkpoint-style prefix
+    eng = HieraEngine(cfg, {"image_encoder." + k: v for k, v in sd.items()}, gpu, fold_ln=fold_ln)  # checkpoint-style prefix
     D = vol.shape[0]
     outs = [torch.zeros(D, cfg.d_model, g, g, dtype=torch.float16, device=gpu) for g in eng.grids[: eng.n_levels()]]
     for d0 in range(0, D, 3):  # slice batches must not change the result
         eng.encode(vol[d0 : d0 + 3].to(gpu), outs, d0)
     data = (vol.float() / 255.0 if vol.dtype == torch.uint8 else vol.float())[None, :, None].repeat(1, 1, 3, 1, 1)
     ref = oh.sam_features(ocfg, sd, data)
-    ref["emu_fpn"] = [t.numpy() for t in oh.forward_features_bf16_storage(ocfg, sd, data)["backbone_fpn"]]  # same storage plan, exact arithmetic
+    emu = oh.forward_features_folded_storage if fold_ln else oh.forward_features_bf16_storage  # the engine's storage plan, exact arithmetic
+    ref["emu_fpn"] = [t.numpy() for t in emu(ocfg, sd, data)["backbone_fpn"]]
     return eng, outs, ref
 
 
@@ -160,13 +161,14 @@ def _check_level(lvl, got, ref, emu):
     assert e_emu.mean() <= e_store.mean() + 1e-4 and e_emu.max() <= 1.25 * e_store.max() + 1e-2 * scale, stats
 
 
+@pytest.mark.parametrize("fold_ln", [True, False])
 @pytest.mark.parametrize("H", [128, 96])
-def test_hiera_encoder_vs_oracle(gpu, H):
+def test_hiera_encoder_vs_oracle(gpu, H, fold_ln):
     """Whole image encoder (patch embed, 8 blocks incl. three q-pooled transitions and global blocks, 4-level neck with the
     top-down path, scalp) vs the fp32 oracle; H = 96 exercises the bilinear resize to the encoder's 128x128."""
     rng = np.random.default_rng(H)
     vol = torch.from_numpy(rng.integers(0, 256, (4, H, H), dtype=np.uint8))
-    eng, outs, ref = _encoder_case(gpu, vol)
+    eng, outs, ref = _encoder_case(gpu, vol, fold_ln=fold_ln)
     assert [tuple(o.shape) for o in outs] == [(4, 256, 32, 32), (4, 256, 16, 16), (4, 256, 8, 8)]
     for lvl, (o, r) in enumerate(zip(outs, ref["backbone_fpn"])):
         # bf16 GEMM operands / fp32 accumulation and residual stream: the ViT path's tolerance (round 3: was 1.5x / 2x of it)
@@ -208,7 +210,7 @@ def test_sam_features_entry_point_hiera_l(gpu, tmp_path):
     pick = [0, 4]  # both sides of the slice batch of 4
     data = torch.from_numpy(vol[pick].astype(np.float32) / 255.0)[None, :, None].repeat(1, 1, 3, 1, 1)
     ref = oh.sam_features(oh.HIERA_L, sd, data)
-    emu = [t.numpy() for t in oh.forward_features_bf16_storage(oh.HIERA_L, sd, data)["backbone_fpn"]]
+    emu = [t.numpy() for t in oh.forward_features_folded_storage(oh.HIERA_L, sd, data)["backbone_fpn"]]  # the shipped storage plan
     for lvl, g in enumerate((128, 64, 32)):
         got = io.read_dataset(out, f"sam_features/backbone_fpn/{lvl}")
         assert got.dtype == np.float16 and got.shape == (5, 256, g, g)

@@ -28,9 +28,21 @@ qk = (torch.randn(ops.alloc_rows(M), 2 * C, device=dev, generator=g) * 0.5).to(t
 vt = torch.randn(slices, heads, 64, kp, device=dev, generator=g).to(torch.bfloat16)
 out = torch.zeros(ops.alloc_rows(M), C, dtype=torch.bfloat16, device=dev)
 fl = 4.0 * nt * nt * 64 * heads * slices
+qkv = torch.cat([qk[:, : 2 * C], (torch.randn(qk.shape[0], C, device=dev, generator=g)).to(torch.bfloat16)], dim=1).contiguous()  # Q | K | V row-major
 res = {}
 for r in range(args.rounds):
     for v in [int(x) for x in args.variants.split(",")]:
+        if v == 1007:  # the shipped form: V row-major in the qkv buffer (cvx_attention_qkv_bf16, variant 7 arithmetic)
+            _lib.set_option("attn_mfma_prio", 2)
+            ops.attention_qkv(qkv, out, slices=slices, heads=heads, ntok=nt, ntp=ntp)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                ops.attention_qkv(qkv, out, slices=slices, heads=heads, ntok=nt, ntp=ntp)
+            e.record()
+            torch.cuda.synchronize()
+            res.setdefault(v, []).append(s.elapsed_time(e) / 3)
+            continue
         _lib.set_option("attn_variant", v % 100)
         _lib.set_option("attn_xcd_remap", 0 if 100 <= v < 200 else 1)  # variant + 100 = same kernel without the XCD block remap
         _lib.set_option("attn_mfma_prio", v // 200)                   # variant + 200 p = s_setprio 1 around the MFMA blocks (p bit 0: S^T, bit 1: O^T)

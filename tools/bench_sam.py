@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slice-batch", type=int, default=64)
     ap.add_argument("--depth", type=int, default=128)
+    ap.add_argument("--no-fold", action="store_true", help="round 2's plan: fp32 stream + LayerNorm kernels in every stage")
     ap.add_argument("--opt", action="append", default=[], help="NAME=VALUE passed to cvx_set_option (A/B runs)")
     a = ap.parse_args()
     from cryovit_amd import _lib
@@ -29,7 +30,7 @@ def main():
         _lib.set_option(k, int(v))
 
     dev = torch.device("cuda:0")
-    enc = load_sam_encoder("SAM2", synthetic_seed=2, device=dev, slice_batch=a.slice_batch)
+    enc = load_sam_encoder("SAM2", synthetic_seed=2, device=dev, slice_batch=a.slice_batch, fold_ln=not a.no_fold)
     vol = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (a.depth, 512, 512), dtype=np.uint8)).to(dev)
     outs = enc._outs(a.depth)
 
