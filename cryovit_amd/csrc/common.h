@@ -83,22 +83,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // wave-uniform LDS byte address.  The builtin above takes a per-lane 64-bit pointer: every piece then costs a 64-bit VALU add
 // (v_lshl_add_u64) right in front of it, inside the MFMA segment of the GEMM / attention loops -- measured on the 256x256 GEMM
 // tile: 2810 -> 2573 cycles per K tile from this change alone.  M0 (the LDS address) is written in the SAME asm statement
-// that uses it; a kernel that uses these helpers must not also use the builtin form (hipcc tracks what IT last wrote to M0).
+// that uses it and M0 is declared clobbered: hipcc may not assume it still holds what the compiler last put there.
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(CVX_LDS_AS const char*)p; }
 __device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 // two pieces from one base: lane offsets voff0 / voff1, LDS destinations lds_dst and lds_dst + STEP bytes
 template <int STEP>
 __device__ __forceinline__ void glds16_saddr2(const void* sbase, uint32_t voff0, uint32_t voff1, uint32_t lds_dst) {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
                  "s_add_u32 m0, m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 ::"v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_dst), "i"(STEP) : "memory");
+                 ::"v"(voff0), "v"(voff1), "s"(sbase), "s"(lds_dst), "i"(STEP) : "memory", "m0");
 }
 
 // per-lane 64-bit source address (gathers whose lanes cannot share a base), same M0 discipline
 __device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 
 // Streaming (non-temporal) 16-B accesses for tensors that are written once and read once by a later kernel: the

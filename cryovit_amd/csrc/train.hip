@@ -113,8 +113,10 @@ __device__ __forceinline__ void focal_terms(float x, float t, float alpha, float
     const float pt = p * t + (1.0f - p) * (1.0f - t);
     const float m = 1.0f - pt;
     const float at = alpha * t + (1.0f - alpha) * (1.0f - t);
-    const float mg1 = gamma == 2.0f ? m : powf(fmaxf(m, 1e-30f), gamma - 1.0f);  // m^(gamma-1)
-    const float mg = mg1 * m;
+    // m^(gamma-1) and m^gamma.  gamma == 0 is plain weighted cross-entropy: m^0 = 1 also at m = 0 (the product form
+    // m^(-1) * m gave 0 there), and the d m^gamma term vanishes
+    const float mg1 = gamma == 2.0f ? m : (gamma == 0.0f ? 0.0f : powf(fmaxf(m, 1e-30f), gamma - 1.0f));
+    const float mg = gamma == 0.0f ? 1.0f : mg1 * m;
     loss = at * mg * ce;
     const float dm = -(2.0f * t - 1.0f) * p * (1.0f - p);
     dldx = at * (gamma * mg1 * dm * ce + mg * (p - t));
