@@ -815,7 +815,10 @@ extern "C" int cvx_set_option(const char* name, int value) {
     }
     else if (!strcmp(name, "conv_wide")) g_conv_wide = value != 0;
     else if (!strcmp(name, "convt_small")) g_convt_small = value != 0;
-    else if (!strcmp(name, "win_attn_prefetch")) g_win_attn_prefetch = value != 0;
+    else if (!strcmp(name, "win_attn_prefetch")) {
+        if (!one_of({0, 1, 2})) return cvx_fail("set_option: win_attn_prefetch is 0 (off), 1 (one tile ahead) or 2 (two tiles ahead)");
+        g_win_attn_prefetch = value;
+    }
     else if (!strcmp(name, "win_attn_x32")) g_win_attn_x32 = value != 0;
     else if (!strcmp(name, "ln_policy")) {
         if (!one_of({0, 1, 2, 3})) return cvx_fail("set_option: ln_policy is a 2-bit mask (1: cacheable loads, 2: rows walked from the end)");

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_sam_patches(const void* __restrict__ sr
 typedef short v8s __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 cat8(v4s a, v4s b) { return __builtin_bit_cast(bf16x8, v8s{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}); }
 
-template <int DSTEPS, bool PF = false, bool X32 = false>
+template <int DSTEPS, bool PF = false, bool X32 = false, bool PF2 = false>
 __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restrict__ q, long ldq, const uint16_t* __restrict__ k,
                                                        const uint16_t* __restrict__ v, long ldkv, uint16_t* __restrict__ out,
                                                        long ldo, int hd, int heads, int G, int ws, int Gq, int wsq,
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
     // PF: this thread's (at most three) 16-B pieces of a tile: tile row, column, LDS offset -- the same for every tile
     constexpr int NPF = 3;
     [[maybe_unused]] int prow[NPF], pcol[NPF];
-    [[maybe_unused]] uint4 rk[NPF], rv[NPF];
+    // PF2: TWO tiles of look-ahead (two register sets, the tile loop unrolled by two): with one, the 64-key tile's compute time
+    // (~0.35 us) is shorter than the L2 / HBM round trip of the next tile's loads and every tile waits for its data
+    [[maybe_unused]] uint4 rk[NPF], rv[NPF], rk2[PF2 ? NPF : 1], rv2[PF2 ? NPF : 1];
     [[maybe_unused]] const int wsh = 31 - __builtin_clz(ws);
     if constexpr (PF) {
         const int ch16 = hd >> 3;
@@ -163,9 +165,10 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
             pcol[pp] = i < 64 * ch16 ? (i % ch16) * 8 : 0;
             rk[pp] = uint4{0u, 0u, 0u, 0u};
             rv[pp] = uint4{0u, 0u, 0u, 0u};
+            if constexpr (PF2) { rk2[pp] = uint4{0u, 0u, 0u, 0u}; rv2[pp] = uint4{0u, 0u, 0u, 0u}; }
         }
     }
-    [[maybe_unused]] auto prefetch = [&](int k0) {
+    [[maybe_unused]] auto prefetch = [&](int k0, uint4 (&rk)[NPF], uint4 (&rv)[NPF]) {
         const int nkt = min(64, nk - k0);
 #pragma unroll
         for (int pp = 0; pp < NPF; ++pp) {
@@ -176,8 +179,9 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
             rv[pp] = *(const uint4*)(v + krow * ldkv + (long)head * hd + pcol[pp]);
         }
     };
-    if constexpr (PF) prefetch(0);
-    for (int k0 = 0; k0 < nk; k0 += 64) {
+    if constexpr (PF) prefetch(0, rk, rv);
+    if constexpr (PF2) { if (nk > 64) prefetch(64, rk2, rv2); }
+    auto tile = [&](int k0, uint4 (&rk)[NPF], uint4 (&rv)[NPF]) {
         const int nkt = min(64, nk - k0), nsub = nkt >> 4;
         __syncthreads();  // previous tile fully consumed (also orders the pad zeroing before the first reads)
         if constexpr (PF) {
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
         }
         __syncthreads();
         if constexpr (PF) {
-            if (k0 + 64 < nk) prefetch(k0 + 64);  // in flight while this tile is consumed
+            if (k0 + (PF2 ? 128 : 64) < nk) prefetch(k0 + (PF2 ? 128 : 64), rk, rv);  // in flight while this tile (and, PF2, the next) is consumed
         }
 
         f32x4 sacc[4];
@@ -298,6 +302,15 @@ __global__ __launch_bounds__(256) void k_win_attention(const uint16_t* __restric
             if (nsub > 2) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][2], pf[2], o[t], 0, 0, 0);
             if (nsub > 3) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf[t][3], pf[3], o[t], 0, 0, 0);
         }
+    };
+    if constexpr (PF2) {
+        static_assert(PF, "PF2 extends PF");
+        for (int k0 = 0; k0 < nk; k0 += 128) {
+            tile(k0, rk, rv);
+            if (k0 + 64 < nk) tile(k0 + 64, rk2, rv2);
+        }
+    } else {
+        for (int k0 = 0; k0 < nk; k0 += 64) tile(k0, rk, rv);
     }
     if (!q_ok) return;
     const float inv = 1.0f / l;
@@ -400,7 +413,8 @@ __global__ __launch_bounds__(256) void k_fpn_out(const float* __restrict__ lat, 
 
 using namespace cvx;
 
-std::atomic<int> g_win_attn_prefetch{1};  // cvx_set_option("win_attn_prefetch", 0 / 1) -- gemm.hip
+std::atomic<int> g_win_attn_prefetch{1};  // cvx_set_option("win_attn_prefetch", 0 / 1 / 2): K / V register prefetch, one tile ahead (default) or two (measured
+                                          // 104.5 -> 106.9 ms per tomogram: 164 VGPRs, a wave per SIMD less) -- gemm.hip
 std::atomic<int> g_win_attn_x32{0};       // cvx_set_option("win_attn_x32", 0 / 1): 16x16x32 products.  Parity-green, measured 113.4 -> 115.4 ms per tomogram on
                                           // sam_features (the kernel is not matrix-pipe bound: wider padded rows cost more than the halved MFMA count saves): off
 
@@ -432,11 +446,14 @@ extern "C" int cvx_window_attention_bf16(const void* q, long ldq, const void* k,
     // register-prefetch form: full 256-thread blocks, 16-B pieces (head_dim % 8, row starts 16-B aligned), power-of-two window
     const bool pf = g_win_attn_prefetch && threads.x == 256 && head_dim % 8 == 0 && ldkv % 8 == 0 && (window & (window - 1)) == 0 &&
                     ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
+    const bool pf2 = pf && g_win_attn_prefetch >= 2 && nk > 64;  // two tiles of look-ahead (windows of more than one 64-key tile)
     // 16x16x32 products: 16-B aligned 8-element pieces of Q and of the staged rows
     const bool x32 = g_win_attn_x32 && head_dim % 8 == 0 && ldq % 8 == 0 && ((uintptr_t)q & 15) == 0;
 #define CVX_WIN_LAUNCH(DS)                                                                                                          \
     do {                                                                                                                            \
-        if (x32 && pf) hipLaunchKernelGGL((k_win_attention<DS, true, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
+        if (pf2 && !x32) hipLaunchKernelGGL((k_win_attention<DS, true, false, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
+                                    head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                  \
+        else if (x32 && pf) hipLaunchKernelGGL((k_win_attention<DS, true, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
                                     head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                  \
         else if (x32) hipLaunchKernelGGL((k_win_attention<DS, false, true>), blocks, threads, 0, st, qq, ldq, kk, vv, ldkv, (uint16_t*)out, ldo, \
                                     head_dim, heads, grid, window, q_grid, q_window, scale_log2e);                                  \
