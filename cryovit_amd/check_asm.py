@@ -1,4 +1,5 @@
-"""Static check of the persistent GEMM tile kernels (csrc/gemm256p.h) in the emitted gfx950 assembly.
+"""Static check of the persistent GEMM tile kernels (csrc/gemm256p.h) -- and, for the M0 / DMA rules, of every other kernel
+that uses the LDS-DMA helpers -- in the emitted gfx950 assembly.
 
 The kernel counts its own vector-memory operations in hand-written ``s_waitcnt vmcnt(N)`` waits, so three properties of
 the COMPILED code are part of its correctness and are asserted here (``python -m cryovit_amd.check_asm``, run by the CPU
@@ -59,9 +60,50 @@ def check_gemm256p(asm: str) -> list[str]:
     return report
 
 
+def check_dma_users(asm: str, fname: str) -> list[str]:
+    """Every other kernel that uses the LDS-DMA helpers of common.h (attention, the marching / tiled convolutions, the one-shot
+    GEMM tiles): the DMA instructions and every access to M0 sit inside inline-asm statements (hipcc brackets those with
+    ``;;#ASMSTART`` / ``;;#ASMEND``), i.e. the compiler never emits a DMA of its own (the builtin form) and never writes or
+    caches M0 itself; and no kernel of the file spills to scratch."""
+    report, inside, kernel, n_dma = [], False, None, {}
+    for ln in asm.splitlines():
+        t = ln.strip()
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            kernel = m.group(1)
+        if "#ASMSTART" in t:
+            inside = True
+        elif "#ASMEND" in t:
+            inside = False
+        elif t and not t.startswith((";", ".", "//")):
+            if "global_load_lds" in t:
+                n_dma[kernel] = n_dma.get(kernel, 0) + 1
+            if not inside:
+                assert "global_load_lds" not in t, f"{fname}:{kernel}: compiler-generated LDS-DMA: {t}"
+                assert not re.search(r"\bm0\b", t), f"{fname}:{kernel}: M0 touched outside inline asm: {t}"
+    for m in re.finditer(r"\.amdhsa_kernel (\w+)(.*?)\.end_amdhsa_kernel", asm, re.S):
+        name, desc = m.group(1), m.group(2)
+        if name not in n_dma:
+            continue
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc).group(1))
+        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1))
+        assert scratch == 0, f"{fname}:{name}: {scratch} B of scratch in a kernel with counted vector-memory waits"
+        report.append(f"{fname:16s} {name[:60]:60s} vgpr {vgpr:3d} dma {n_dma[name]:3d}")
+    return report
+
+
+DMA_SOURCES = ("attention.hip", "conv_halo.hip")  # (conv_halo: kernels only in the ablation build)
+
+
 def main() -> None:
-    for line in check_gemm256p(compile_asm(CSRC / "gemm.hip")):
+    gemm_asm = compile_asm(CSRC / "gemm.hip")
+    for line in check_gemm256p(gemm_asm):
         print(line)
+    for line in check_dma_users(gemm_asm, "gemm.hip"):
+        print(line)
+    for f in DMA_SOURCES:
+        for line in check_dma_users(compile_asm(CSRC / f), f):
+            print(line)
     print("ok")
 
 

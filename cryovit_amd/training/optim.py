@@ -30,7 +30,7 @@ class AdamW:
         for p in self.params:
             offs.append(n)
             n += (p.numel() + 3) // 4 * 4  # slices stay 16-B aligned
-        self.n = n
+        self.n, self.offsets = n, offs
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros_like(self.flat_p)
         self.exp_avg = torch.zeros_like(self.flat_p)
@@ -45,17 +45,43 @@ class AdamW:
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.flat_g.zero_()  # (the .grad views stay attached: autograd accumulates in place)
 
+    def _check_attached(self) -> None:
+        """Parameters and gradients must still be the slices handed out at construction: ``model.zero_grad()`` (set_to_none),
+        ``model.to()`` / ``half()`` or a ``load_state_dict(assign=True)`` replace them, and the kernel would then step stale
+        buffers.  A dropped ``.grad`` (None) is re-attached -- the buffer slice is zero after ``zero_grad`` either way;
+        anything else is an error."""
+        esz = self.flat_p.element_size()
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if p.data_ptr() != self.flat_p.data_ptr() + o * esz or p.dtype != torch.float32:
+                raise RuntimeError(f"AdamW: parameter {i} no longer lives in the optimizer's flat buffer (moved or cast "
+                                   f"after the optimizer was built); rebuild the optimizer")
+            if p.grad is None:
+                self.flat_g[o : o + p.numel()].zero_()
+                p.grad = self.flat_g[o : o + p.numel()].view(p.shape)
+            elif p.grad.data_ptr() != self.flat_g.data_ptr() + o * esz:
+                raise RuntimeError(f"AdamW: the gradient of parameter {i} was replaced (use this optimizer's zero_grad, or "
+                                   f"zero_grad(set_to_none=True) which is re-attached); rebuild the optimizer")
+
     @torch.no_grad()
     def step(self) -> None:
+        """One fused launch.  The optimizer is standalone (there is no HIP backward yet, SURVEY s.8f N4): engines that cache
+        packed weights (``model._engine``) are not invalidated here -- drop them after a step (``model._engine = None``)."""
+        self._check_attached()
         self.step_count += 1
         ops.adamw_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, lr=self.lr, beta1=self.beta1, beta2=self.beta2,
                        eps=self.eps, weight_decay=self.weight_decay, step=self.step_count)
 
     def state_dict(self) -> dict:
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+        return {"n": self.n, "offsets": list(self.offsets), "shapes": [tuple(p.shape) for p in self.params],
+                "step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "lr": self.lr, "betas": (self.beta1, self.beta2), "eps": self.eps, "weight_decay": self.weight_decay}
 
     def load_state_dict(self, sd: dict) -> None:
+        if "n" in sd and (int(sd["n"]) != self.n or list(sd["offsets"]) != list(self.offsets)
+                          or [tuple(x) for x in sd["shapes"]] != [tuple(p.shape) for p in self.params]):
+            raise ValueError("AdamW.load_state_dict: the flat parameter layout of the checkpoint differs from this optimizer's")
+        if sd["exp_avg"].numel() != self.n or sd["exp_avg_sq"].numel() != self.n:
+            raise ValueError("AdamW.load_state_dict: moment buffers of the wrong size")
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])

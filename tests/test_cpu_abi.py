@@ -72,5 +72,11 @@ def test_persistent_gemm_kernels_static_properties():
     from cryovit_amd import check_asm
     from cryovit_amd.build import CSRC
 
-    report = check_asm.check_gemm256p(check_asm.compile_asm(CSRC / "gemm.hip"))
+    gemm_asm = check_asm.compile_asm(CSRC / "gemm.hip")
+    report = check_asm.check_gemm256p(gemm_asm)
     assert len(report) >= 10 and any("EpiSwiGLU" in r and "FULL" in r for r in report)
+    # the other users of the LDS-DMA helpers: M0 and the DMA only inside inline asm, no scratch
+    others = check_asm.check_dma_users(gemm_asm, "gemm.hip")
+    for f in check_asm.DMA_SOURCES:
+        others += check_asm.check_dma_users(check_asm.compile_asm(CSRC / f), f)
+    assert any("k_attentionILi7" in r for r in others) and any("k_conv3_march" in r for r in others)

@@ -116,6 +116,38 @@ def test_optimisation_loop_dice_plus_adamw(gpu):
     assert w_gpu[0].data_ptr() == opt_g.flat_p.data_ptr()  # the parameter IS a view of the flat buffer
 
 
+def test_adamw_stays_attached_or_raises(gpu):
+    """Gradients dropped by ``zero_grad(set_to_none=True)`` are re-attached to the flat buffer (the step still sees what
+    autograd then accumulates); a parameter or gradient that moved away from its slice is an error, not a silent no-op; the
+    state dict carries the flat layout and a foreign one is refused."""
+    from cryovit_amd.training.optim import AdamW
+
+    lin = torch.nn.Linear(5, 3).to(gpu)
+    opt = AdamW(lin.parameters(), lr=1e-1, weight_decay=0.0)
+    x = torch.randn(7, 5, device=gpu)
+    lin.zero_grad(set_to_none=True)          # torch's default: .grad = None
+    opt.step()                               # re-attaches, steps with zero gradients: parameters unchanged
+    assert all(p.grad is not None and p.grad.data_ptr() == opt.flat_g.data_ptr() + o * 4 for p, o in zip(opt.params, opt.offsets))
+    before = opt.flat_p.clone()
+    lin(x).square().sum().backward()         # accumulates into the re-attached slices
+    assert float(opt.flat_g.abs().sum()) > 0
+    opt.step()
+    assert not torch.equal(opt.flat_p, before)
+    sd = opt.state_dict()
+    assert sd["n"] == opt.n and sd["offsets"] == opt.offsets
+    opt.load_state_dict(sd)
+    other = AdamW(torch.nn.Linear(5, 4).to(gpu).parameters())
+    with pytest.raises(ValueError):
+        other.load_state_dict(sd)
+    lin.weight.grad = torch.zeros_like(lin.weight)  # a replaced gradient tensor
+    with pytest.raises(RuntimeError):
+        opt.step()
+    lin.weight.grad = None
+    lin.weight.data = lin.weight.data.clone()       # a moved parameter (model.to(), assign=True load ...)
+    with pytest.raises(RuntimeError):
+        opt.step()
+
+
 @pytest.mark.parametrize("gamma", [2, 1.5])
 def test_focal_loss_against_oracle(gpu, gamma):
     """FocalLoss (losses.py:35-64) against the oracle restatement of torchvision's sigmoid_focal_loss (float64): value and autograd
