@@ -294,6 +294,72 @@ def cpu_baseline() -> dict:
     }
 
 
+class BoardSampler:
+    """Shader clock and board power of THIS rank's GPU over the timed region, from the amdgpu sysfs files (hwmon freq1_input /
+    power1_average, the card matched by PCI bus id), sampled every 50 ms by a thread that touches no GPU API.  The MFMA peak the
+    roofline is priced at (2.5 PFLOP/s) assumes 2.4 GHz; under this workload the board sits at its power limit and holds a lower
+    clock (`profiles/r03_clocks_power.txt`, `profiles/r03_mfma_power.txt`), which the line reports beside the fraction.  Every
+    field is None when sysfs is not readable."""
+
+    def __init__(self, dev_index: int) -> None:
+        import glob
+        import threading
+
+        import torch
+
+        self.hw, self.mhz, self.watts, self.on = None, [], [], False
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+            for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+                if want in os.path.realpath(d):
+                    hw = sorted(glob.glob(d + "/hwmon/hwmon*"))
+                    self.hw = hw[0] if hw else None
+        except (AttributeError, OSError, RuntimeError) as e:  # a missing attribute or an unreadable sysfs only drops the optional fields
+            print(f"[bench] board sampler off: {e}", file=sys.stderr)
+            self.hw = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                v = f.read().strip()
+            return float(v) if v else None
+        except (OSError, ValueError):
+            return None
+
+    def _run(self) -> None:
+        while self.on:
+            f = self._read(f"{self.hw}/freq1_input")
+            w = self._read(f"{self.hw}/power1_average") or self._read(f"{self.hw}/power1_input")
+            if f:
+                self.mhz.append(f / 1e6)
+            if w:
+                self.watts.append(w / 1e6)
+            time.sleep(0.05)
+
+    def start(self) -> None:
+        if self.hw:
+            self.on = True
+            self._thread.start()
+
+    def stop(self) -> dict:
+        if self.on:
+            self.on = False
+            self._thread.join()
+
+        def med(xs):
+            return sorted(xs)[len(xs) // 2] if xs else None
+
+        mhz = med(self.mhz)
+        return {"sclk_mhz_median": mhz, "sclk_mhz_min": min(self.mhz) if self.mhz else None, "power_w_median": med(self.watts),
+                "samples": len(self.mhz), "nominal_sclk_mhz": 2400,
+                "mfma_peak_at_held_clock_tflops": PEAK_BF16_TFLOPS * mhz / 2400.0 if mhz else None,
+                "note": "amdgpu sysfs over the timed region; the board holds its power limit by lowering the clock under MFMA load "
+                        "(MFMA-only loops on normal(0,1) bf16 operands sustain 1.77-1.85 PFLOP/s on these boards: profiles/r03_mfma_power.txt)"}
+
+
 def measured_traffic() -> dict:
     """PMC traffic of the dominant kernel, per launch, from the committed rocprofv3 --pmc passes (collected on the GPU box with
     tools/profile_round.sh, condensed by tools/summarize_profiles.py; `rocprofv3` cannot run inside this process).  The JSON names
@@ -464,6 +530,8 @@ def main() -> None:
         out = step()
     step_no[0] = 0
     sync_all()
+    board = BoardSampler(dev.index or 0)
+    board.start()
     kt.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -471,6 +539,7 @@ def main() -> None:
     sync_all()
     elapsed = time.perf_counter() - t0
     kt.stop()
+    board_stats = board.stop()
     k_ms = kt.mean_ms()
     n_launch = kt.n
 
@@ -508,6 +577,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": "k_gemm256p_nreg<EpiSwiGLUT<LN>, FULL>: w12 GEMM 1536->8192, LayerNorm folded into the epilogue + fused SiLU gate", "achieved": achieved,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, **measured_traffic(),
                          "launches_timed": n_launch, "avg_launch_ms": k_ms, "flops_per_launch": k_flops},
+            "board": board_stats,
         }
         if per_rank is not None:
             line["per_rank_voxels_per_s"] = per_rank
