@@ -215,12 +215,16 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
         // ---- S^T[t] = K_t Q^T : rows = keys (registers), col = query (lane) ----
         f32x16 s[2];
         const int kv0 = j * KV_TILE;
+        // 1029 keys = 16 x 64 + 5: the upper 32 keys of the last tile are all padding.  Their products, S^T and O^T alike, are
+        // skipped (wave-uniform): half a tile of MFMAs in 17, which at the board's power limit is time
+        const bool half_tile = !(xcd_remap & 8) && kv0 + 32 >= ntok;  // (bit 3: A/B switch, cvx_set_option "attn_half_tile" 0)
         auto compute_s = [&]() {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = 0.f; }
             if (prio_qk) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                if (t == 1 && half_tile) break;  // (the mask below sets all of S^T[1] to -inf)
                 if constexpr (AUG) s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kaug, qaug, s[t], 0, 0, 0);  // -m_used for every key
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
@@ -354,7 +358,8 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
         // ---- O^T[dt] += V^T[dt] P^T : accumulator registers 8s..8s+7 of S^T[t] are k-step s of the B operand ----
         if (prio_pv) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
+            if (t == 1 && half_tile) break;  // P is exactly 0 there
 #pragma unroll
             for (int sk = 0; sk < 2; ++sk) {
                 bf16x8 pf;
@@ -375,6 +380,7 @@ __global__ __launch_bounds__((VARIANT == 8 || VARIANT == 9) ? 512 : ATT_THREADS)
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
             }
+        }
         if (prio_pv) __builtin_amdgcn_s_setprio(0);
     }
 
@@ -571,6 +577,7 @@ using namespace cvx;
 
 std::atomic<int> g_attn_variant{7};     // cvx_set_option("attn_variant"); 7 = maximum subtracted inside the product, re-anchoring triggered by the probability sums (default); 6 = by the tile maxima
 std::atomic<int> g_attn_xcd_remap{1};   // cvx_set_option("attn_xcd_remap")
+std::atomic<int> g_attn_half_tile{1};   // cvx_set_option("attn_half_tile"): skip the all-padding upper half of the last key tile (0: A/B runs)
 std::atomic<int> g_attn_mfma_prio{2};   // cvx_set_option("attn_mfma_prio"): s_setprio 1 around the wave's MFMA blocks (bit 0: S^T, bit 1: O^T).  Measured per layer:
                                         // 0: 1.028 ms, 1: 1.018, 2: 0.999 (default), 3: 1.003 -- the O^T MFMAs wait behind other waves' softmax VALU otherwise
 
@@ -583,7 +590,7 @@ extern "C" int cvx_attention_qkv_bf16(const void* qkv, long ld, void* out, long 
     const int nqb = (ntok + 127) / 128;
     const long nblk = (long)nqb * heads * slices;
     if (nblk > 0x7fffffff) return cvx_fail("attention_qkv: grid too large");
-    const int xcd_remap = (((long)heads * slices) % 8 == 0 && g_attn_xcd_remap ? 1 : 0) | ((g_attn_mfma_prio.load() & 3) << 1);
+    const int xcd_remap = (((long)heads * slices) % 8 == 0 && g_attn_xcd_remap ? 1 : 0) | ((g_attn_mfma_prio.load() & 3) << 1) | (g_attn_half_tile.load() ? 0 : 8);
     hipLaunchKernelGGL((k_attention<7, true>), dim3((unsigned)nblk), dim3(ATT_THREADS), 0, st, (const uint16_t*)qkv, ld, (const uint16_t*)nullptr,
                        (uint16_t*)out, ldo, heads, ntok, ntp, /*kp (unused)*/ 0, heads * 64, nqb, xcd_remap);
     return cvx_check_launch();
@@ -603,7 +610,7 @@ extern "C" int cvx_attention_bf16(const void* qk, long ldqk, const void* vt, voi
     const int nqb = (ntok + rows_per_block - 1) / rows_per_block;
     const long nblk = (long)nqb * heads * slices;
     if (nblk > 0x7fffffff) return cvx_fail("attention: grid too large");
-    const int xcd_remap = (((long)heads * slices) % 8 == 0 && g_attn_xcd_remap ? 1 : 0) | ((g_attn_mfma_prio.load() & 3) << 1);
+    const int xcd_remap = (((long)heads * slices) % 8 == 0 && g_attn_xcd_remap ? 1 : 0) | ((g_attn_mfma_prio.load() & 3) << 1) | (g_attn_half_tile.load() ? 0 : 8);
     dim3 grid((unsigned)nblk);
     void (*k)(const uint16_t*, long, const uint16_t*, uint16_t*, long, int, int, int, int, int, int, int);
     switch (variant) {

@@ -739,7 +739,7 @@ int convt_small_dispatch(const cvx_gemm_desc& d, hipStream_t st);
 
 using namespace cvx;
 
-extern std::atomic<int> g_attn_variant, g_attn_xcd_remap, g_attn_mfma_prio;  // attention.hip
+extern std::atomic<int> g_attn_variant, g_attn_xcd_remap, g_attn_mfma_prio, g_attn_half_tile;  // attention.hip
 extern std::atomic<int> g_ln_policy;                         // norm.hip
 extern std::atomic<int> g_win_attn_prefetch, g_win_attn_x32; // hiera.hip
 
@@ -830,6 +830,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
         g_attn_variant = value;
     } else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value != 0;
     else if (!strcmp(name, "attn_mfma_prio")) g_attn_mfma_prio = value & 3;
+    else if (!strcmp(name, "attn_half_tile")) g_attn_half_tile = value != 0;
     else if (!strcmp(name, "tile_group_l")) {
         if (value < 1) return cvx_fail("set_option: tile_group_l must be >= 1");
         g_tile_group_l_host = value;

@@ -32,8 +32,10 @@ qkv = torch.cat([qk[:, : 2 * C], (torch.randn(qk.shape[0], C, device=dev, genera
 res = {}
 for r in range(args.rounds):
     for v in [int(x) for x in args.variants.split(",")]:
-        if v == 1007:  # the shipped form: V row-major in the qkv buffer (cvx_attention_qkv_bf16, variant 7 arithmetic)
+        if v in (1007, 1008):  # the shipped form: V row-major in the qkv buffer (cvx_attention_qkv_bf16, variant 7 arithmetic); 1008: without the half-tile skip
+            _lib.set_option("attn_variant", 7)
             _lib.set_option("attn_mfma_prio", 2)
+            _lib.set_option("attn_half_tile", 1 if v == 1007 else 0)
             ops.attention_qkv(qkv, out, slices=slices, heads=heads, ntok=nt, ntp=ntp)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
