@@ -252,7 +252,7 @@ def attn_variant(request):
 
 
 @pytest.mark.parametrize("attn_variant", [0, 3, 4, 5, 6, 7, 8, 9], indirect=True)
-@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1)])
+@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1), (96, 2, 1), (100, 2, 1), (128, 1, 2)])
 def test_attention(gpu, nt, slices, heads, attn_variant):
     from cryovit_amd.engine import ops
 
@@ -279,7 +279,8 @@ def test_attention(gpu, nt, slices, heads, attn_variant):
     assert torch.all(got[:, nt:] == 0), "padding rows must not be written"
 
 
-@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1), (133, 2, 1)])
+@pytest.mark.parametrize("nt,slices,heads", [(29, 3, 2), (261, 2, 6), (1029, 2, 3), (1029, 8, 1), (133, 2, 1),
+                                             (96, 2, 1), (100, 2, 1), (128, 1, 2)])  # (last key tile: exactly half / more than half / all valid)
 def test_attention_qkv_row_major_v(gpu, nt, slices, heads):
     """cvx_attention_qkv_bf16: Q | K | V row-major in ONE buffer (the output of a single qkv GEMM); V fragments are transposed by the
     LDS reads (ds_read_b64_tr_b16).  Same reference and tolerance as test_attention; junk in the pad rows must not leak."""
