@@ -85,4 +85,5 @@ for r in range(args.rounds):
 valid_rows = M
 for name, (epi, K, N) in shapes.items():
     fl = 2.0 * valid_rows * K * N
-    print(name, "  ".join(f"v{v[0]}s{v[1]}: {fl / (sorted(res[(name, v)])[len(res[(name, v)]) // 2] * 1e-3) / 1e12:7.1f} TF (min {fl / (min(res[(name, v)]) * 1e-3) / 1e12:6.1f}..)" for v in variants))
+    label = (lambda v: f"group_l {v}") if groups else (lambda v: f"v{v[0]}s{v[1]}")
+    print(name, "  ".join(f"{label(v)}: {fl / (sorted(res[(name, v)])[len(res[(name, v)]) // 2] * 1e-3) / 1e12:7.1f} TF (min {fl / (min(res[(name, v)]) * 1e-3) / 1e12:6.1f}..)" for v in variants))

@@ -137,6 +137,18 @@ def main():
     del sgn_a, sgn_w, pow_a, pow_w
     phase("w12 GEMM (random operands)", lambda: ops.gemm(EPI_SWIGLU, a, w, out, bc, m=M, n=N, ln_rowstat=rowstat), sampler)
     phase("1-GiB device copy", lambda: big2.copy_(big), sampler)
+    for mib in (64, 16, 2):  # working sets inside the Infinity Cache (256 MiB) / inside the L2s (8 x 4 MiB): the cost of a byte by where it comes from
+        n = mib << 20
+        srcs = [big[i * n:(i + 1) * n] for i in range(1)]
+        dsts = [big2[i * n:(i + 1) * n] for i in range(1)]
+        reps = max(1, (1 << 30) // n // 8)
+
+        def small_copy(srcs=srcs, dsts=dsts, reps=reps):
+            for _ in range(reps):
+                dsts[0].copy_(srcs[0])
+
+        t0 = time.time()
+        phase(f"{mib}-MiB device copy x{reps}", small_copy, sampler)
     qkv = torch.randn(ops.alloc_rows(128 * 1032), 4608, device=dev, generator=g).to(torch.bfloat16)
     o = torch.empty(ops.alloc_rows(128 * 1032), 1536, dtype=torch.bfloat16, device=dev)
     phase("attention (qkv form)", lambda: ops.attention_qkv(qkv, o, slices=128, heads=24, ntok=1029, ntp=1032), sampler)
