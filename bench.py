@@ -241,6 +241,67 @@ def other_configs(dev, vol) -> dict:
     return out
 
 
+def head_layer_breakdown(head, feats_cl, labels, D: int, hp: int, wp: int) -> list:
+    """configs[2] per layer: the head's launch sequence issued op by op (``HeadEngine._forward_py`` = what ``cvx_head_forward``
+    launches) with a HIP event after each op; per entry the algorithmic FLOPs (2 x MACs) and the compulsory HBM bytes (input read
+    once + output written once, fp16; GroupNorm reads its input twice) turned into TFLOP/s and TB/s.  A GroupNorm entry is
+    three launches (block statistics, finalize, apply)."""
+    import torch
+
+    from cryovit_amd.engine import ops
+
+    marks, wrapped = [], {}
+
+    def ev(label, flops, nbytes):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((label, flops, nbytes, e))
+
+    def wrap(name, describe):
+        orig = getattr(ops, name)
+        wrapped[name] = orig
+
+        def f(*a, **k):
+            orig(*a, **k)
+            ev(*describe(*a, **k))
+
+        setattr(ops, name, f)
+
+    def d_gemm(epi, a, w, out, bias, *, m, n, cout=0, **k):
+        kdim = a.shape[1]
+        what = f"ConvT {kdim}->{cout} x4 +GELU" if cout else f"1x1x1 {kdim}->{n} +GELU"
+        return what, 2.0 * m * kdim * n, 2.0 * m * (kdim + n)
+
+    def d_conv(x, w, bias, out, zp, *, Cin, D, H, W, dil, cout, act):
+        nv = D * H * W
+        return f"conv3 {Cin}->{cout} dil {dil} +GELU @ {H}x{W}", 2.0 * nv * 27 * Cin * cout, 2.0 * nv * (Cin + cout)
+
+    def d_gn(x, w, b, out, stats, *, nvox, Cdim, G, eps, act=0):
+        return f"GroupNorm {Cdim} ch, {G} groups", 0.0, 2.0 * nvox * Cdim * 3
+
+    def d_out(x, w, bias, logits, probs, labels, dice, *, D, H, W, **k):
+        nv, c = D * H * W, head.widths[2]
+        return f"conv3 {c}->1 + clip + sigmoid + Dice @ {H}x{W}", 2.0 * nv * 27 * c, nv * (2.0 * c + 4 + 1)
+
+    try:
+        wrap("gemm", d_gemm)
+        wrap("conv3d", d_conv)
+        wrap("groupnorm", d_gn)
+        wrap("conv3_out_fused", d_out)
+        torch.cuda.synchronize()
+        ev("_start", 0.0, 0.0)
+        head._forward_py(feats_cl, D, hp, wp, labels=labels, want_probs=True)
+    finally:
+        for name, orig in wrapped.items():
+            setattr(ops, name, orig)
+    torch.cuda.synchronize()
+    rows = []
+    for (_, _, _, e0), (label, fl, nb, e1) in zip(marks[:-1], marks[1:]):
+        ms = e0.elapsed_time(e1)
+        rows.append({"op": label, "ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "compulsory_TBps": round(nb / ms / 1e9, 2)})
+    return rows
+
+
 def cpu_baseline() -> dict:
     """torch-CPU fp32 oracle on a bounded sample of the same workload (SURVEY s.8d 'CPU reference timing'): ViT-g/14-reg on
     k = 2 slices of 448x448, the head on [1,1536,128,8,8] (FULL depth, so dilation / padding / GroupNorm behave as in the real
@@ -590,7 +651,8 @@ def main() -> None:
                                                             "tflops": vit.flops(D_, H_, W_) / st["vit_ms"] / 1e9},
                 "configs[2] head fwd + Dice": {"ms": st["head_ms"], "voxels_per_s": voxels / st["head_ms"] * 1e3,
                                                "tflops": head.flops(D_, hp, wp) / st["head_ms"] / 1e9,
-                                               "compulsory_GBps": head_bytes / st["head_ms"] / 1e6, "hbm_peak_GBps": PEAK_HBM_TBS * 1e3},
+                                               "compulsory_GBps": head_bytes / st["head_ms"] / 1e6, "hbm_peak_GBps": PEAK_HBM_TBS * 1e3,
+                                               "layers": head_layer_breakdown(head, feats_cl, labels, D_, hp, wp)},
             }
             if world == 1:
                 try:
