@@ -648,6 +648,7 @@ template <class E> struct epi_can_shift<E, std::void_t<decltype(std::declval<con
 // the N = 1536 GEMMs of one 128-slice batch) is cut into a main launch of whole rounds and a tail launch over the remaining
 // M rows with 128x128 tiles (4x as many, quarter-size tiles: the tail costs ~0.3 of a round instead of a full one).
 static std::atomic<int> g_tail_split{2};  // 2: also for the residual epilogue with a short K loop (proj), which pays off since the tail runs on 64 x 128 tiles
+static std::atomic<int> g_tail_deep{1};  // cvx_set_option("gemm_tail_deep"): tails run on the multi-stage ring (0: the double-buffered tiles, for A/B)
 static std::atomic<int> g_tail_tile{1};  // tail launches: 1 = 64 x 128 tiles (twice the workgroups on the idle chip), 0 = 128 x 128
 static std::atomic<int> g_tail_max{128};  // (64 -> 128 in round 3: 281.26 -> 280.26 ms per tomogram; 0 = never: 282.89) largest last partial round (in 256 x 256 tiles) that is cut off into a tail launch ("gemm_tail_max")
 static long tail_split_rows(long M, long Npad, bool allow = true) {
@@ -679,7 +680,20 @@ static int launch_256_split(const uint16_t* A, long lda, const uint16_t* Wt, lon
         if (m_main < M) {
             int rc = launch_256<Epi, false>(A, lda, Wt, ldw, m_main, Npad, Kpad, epi, st);
             if (rc) return rc;
-            // the tail is a handful of tiles on an otherwise idle chip: latency-bound, so more, smaller workgroups finish sooner
+            // the tail is a handful of tiles on an otherwise idle chip, one workgroup per CU at most: what it waits for is the DMA
+            // round trip of each K tile, so it gets the ring with 2-3 K tiles in flight (gemm_core.h, TileCfg STAGES)
+            const long rows = M - m_main;
+            if (g_tail_deep) {
+                // (the residual GEMMs' tails only: 192 workgroups.  For the qkv / w12 tails -- 288 / 512 workgroups of 128 x 128 -- a
+                //  128 x 256 tile on a 3-deep ring, one workgroup per CU, measured SLOWER than two double-buffered workgroups per
+                //  CU: 34.5 / 36.1 us against 29.1 / 30.7)
+                if constexpr (epi_has_preload<Epi>::value || epi_has_hl<Epi>::value) {
+                    if ((Npad / 64) * ((rows + 127) / 128) <= 256) {
+                        return launch_nreg<TileCfg<64, 128, 1, 4>>(A + m_main * lda, lda, Wt, ldw, rows, Npad, Kpad, epi.shifted(m_main), st);
+                    }
+                }
+            }
+            // (before the ring: more, smaller workgroups finish sooner)
             if (g_tail_tile == 2 && (M - m_main) / 256 * (Npad / 256) * 16 <= 1024)
                 // 64 x 64 tiles, 32 KB of LDS each: three workgroups per CU.  The tail is LATENCY-bound (one K tile of look-ahead, a
                 // K tile per DMA round trip): co-resident workgroups overlap each other's waits
@@ -829,6 +843,7 @@ extern "C" int cvx_set_option(const char* name, int value) {
             return cvx_fail("set_option: unknown attn_variant (ablation variants need a -DCVX_ABLATION build)");
         g_attn_variant = value;
     } else if (!strcmp(name, "attn_xcd_remap")) g_attn_xcd_remap = value != 0;
+    else if (!strcmp(name, "gemm_tail_deep")) g_tail_deep = value != 0;  // 0: double-buffered tail tiles (A/B); a 6-deep ring measured equal to the 4-deep one
     else if (!strcmp(name, "attn_mfma_prio")) g_attn_mfma_prio = value & 3;
     else if (!strcmp(name, "attn_half_tile")) g_attn_half_tile = value != 0;
     else if (!strcmp(name, "tile_group_l")) {

@@ -17,6 +17,7 @@
 //   * K loop: double-buffered, one barrier per 64-deep K tile (next tile's DMA issued before the MFMAs).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace cvx {
 
@@ -148,15 +149,17 @@ struct Conv3Loader {
 // ------------------------------------------------------------------------------------------------
 // Kernel
 // ------------------------------------------------------------------------------------------------
-template <int BR_, int BL_, int WAVES_R_>
+// STAGES > 2: a ring of STAGES K tiles with STAGES - 1 in flight and counted waits -- for launches of at most one workgroup
+// per CU (the tails of the persistent kernel), where nothing else on the CU overlaps the DMA round trip of a K tile
+template <int BR_, int BL_, int WAVES_R_, int STAGES_ = 2>
 struct TileCfg {
-    static constexpr int BR = BR_, BL = BL_, WAVES_R = WAVES_R_, WAVES_L = 4 / WAVES_R_;
+    static constexpr int BR = BR_, BL = BL_, WAVES_R = WAVES_R_, WAVES_L = 4 / WAVES_R_, STAGES = STAGES_;
     static constexpr int WR = BR / WAVES_R, WL = BL / WAVES_L;
     static constexpr int FR = WR / 16, FL = WL / 16;
     static constexpr int FRG = FR > 4 ? 4 : FR;  // sigma group = min(wave tile, 64) rows
     static constexpr int TILE_R_BYTES = BR * 128, TILE_L_BYTES = BL * 128;
     static constexpr int STAGE_BYTES = TILE_R_BYTES + TILE_L_BYTES;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     static_assert(WR % 16 == 0 && WL % 16 == 0, "wave tile must be a multiple of 16");
     static_assert(FR <= 4 || FR % 4 == 0, "R wave tile > 64 must be a multiple of 64");
 };
@@ -197,6 +200,51 @@ __device__ __forceinline__ void gemm_tile_body(const LoaderR& ldr, const LoaderL
     const int offR = wr0 * 128 + fo;
     const int offL = Cfg::TILE_R_BYTES + wl0 * 128 + fo;
 
+    auto mfma_tile = [&](const char* cur) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 rf[FR], lf[FL];
+#pragma unroll
+            for (int a = 0; a < FR; ++a) rf[a] = *(const bf16x8*)(cur + ((offR + a * 2048) ^ (ks << 6)));
+#pragma unroll
+            for (int b = 0; b < FL; ++b) lf[b] = *(const bf16x8*)(cur + ((offL + b * 2048) ^ (ks << 6)));
+#pragma unroll
+            for (int a = 0; a < FR; ++a)
+#pragma unroll
+                for (int b = 0; b < FL; ++b)
+                    acc[a][b] = mfma16x16x32<epi_is_f16<Epi>::value>(rf[a], lf[b], acc[a][b]);
+        }
+    };
+    if constexpr (Cfg::STAGES > 2) {
+        // K tiles kt+1 .. kt+S-2 stay in flight while tile kt is multiplied; every wave issues the same PER pieces per K tile
+        // (both loaders divide evenly), so "tile kt has landed" is vmcnt(PER x tiles issued after it)
+        constexpr int S = Cfg::STAGES, PER = LoaderR::NJ + LoaderL::NJ;
+        static_assert((Cfg::BR * 8) % GEMM_THREADS == 0 && (Cfg::BL * 8) % GEMM_THREADS == 0, "counted waits need whole passes");
+        static_assert(S <= 6 && (S - 2) * PER < 64, "vmcnt is a 6-bit field");
+        auto stage = [&](int kt) { return smem + (kt % S) * Cfg::STAGE_BYTES; };
+        for (int kt = 0; kt < S - 1 && kt < nk; ++kt) {
+            ldr.issue(stage(kt), kt);
+            ldl.issue(stage(kt) + Cfg::TILE_R_BYTES, kt);
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = min(S - 2, nk - 1 - kt);
+            auto wait_ahead = [&](auto tag) {  // (tag::value tiles may stay in flight)
+                constexpr int N = decltype(tag)::value * PER;
+                if constexpr (N < 64) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+            };
+            if (ahead >= 4) wait_ahead(std::integral_constant<int, 4>{});
+            else if (ahead == 3) wait_ahead(std::integral_constant<int, 3>{});
+            else if (ahead == 2) wait_ahead(std::integral_constant<int, 2>{});
+            else if (ahead == 1) wait_ahead(std::integral_constant<int, 1>{});
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // tile kt landed for every wave, and every wave is done with tile kt-1 (whose slot is refilled next)
+            if (kt + S - 1 < nk) {
+                ldr.issue(stage(kt + S - 1), kt + S - 1);
+                ldl.issue(stage(kt + S - 1) + Cfg::TILE_R_BYTES, kt + S - 1);
+            }
+            mfma_tile(stage(kt));
+        }
+    } else {
     ldr.issue(smem, 0);
     ldl.issue(smem + Cfg::TILE_R_BYTES, 0);
     // the LDS-DMA is issued from inline asm (saddr form, common.h), which hipcc's own vmcnt bookkeeping does not see:
@@ -211,21 +259,10 @@ __device__ __forceinline__ void gemm_tile_body(const LoaderR& ldr, const LoaderL
             ldr.issue(nxt, kt + 1);
             ldl.issue(nxt + Cfg::TILE_R_BYTES, kt + 1);
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 rf[FR], lf[FL];
-#pragma unroll
-            for (int a = 0; a < FR; ++a) rf[a] = *(const bf16x8*)(cur + ((offR + a * 2048) ^ (ks << 6)));
-#pragma unroll
-            for (int b = 0; b < FL; ++b) lf[b] = *(const bf16x8*)(cur + ((offL + b * 2048) ^ (ks << 6)));
-#pragma unroll
-            for (int a = 0; a < FR; ++a)
-#pragma unroll
-                for (int b = 0; b < FL; ++b)
-                    acc[a][b] = mfma16x16x32<epi_is_f16<Epi>::value>(rf[a], lf[b], acc[a][b]);
-        }
+        mfma_tile(cur);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // next tile landed and everyone is done reading `cur`
+    }
     }
 
     // epilogue: lane (g = lane>>4) owns R rows [g*4*FRG, +4*FRG) of each 16*FRG-row group, one L row per frag
