@@ -860,11 +860,14 @@ def test_split_stream(gpu, rows, C):
     assert torch.allclose(got[:, 0], rstd, rtol=2e-6, atol=0) and torch.allclose(got[:, 1], -mu * rstd, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("M,N,K", [(700, 384, 256), (300, 128, 192), (2048, 1536, 512), (2311, 512, 256), (5000, 1536, 1536)])
+@pytest.mark.parametrize("M,N,K", [(700, 384, 256), (300, 128, 192), (2048, 1536, 512), (2311, 512, 256), (5000, 1536, 1536),
+                                   (66500, 512, 256), (66300, 512, 128)])
 def test_gemm_resid_hl(gpu, M, N, K):
     """CVX_EPI_RESID_HL: x = hi + lo; x += gamma * (acc + bias); hi', lo' = split(x); stat_part[n/64][m] = row sums of the new x
     over 64-column slots.  Shapes cover the 128-wide tiles (M < 1024), the persistent 256 tile with interior tiles only (2048),
-    with a ragged last M tile (2311) and the main + tail split (5000 x 1536: 20 x 6 tiles)."""
+    with a ragged last M tile (2311), 120 tiles on the persistent kernel (5000 x 1536) and the main + tail split (66500 / 66300 x 512:
+    520 tiles = 2 whole rounds of 256 x 256 tiles + the last 964 / 764 rows on the 64 x 128 tile's 4-deep ring, with a ragged last
+    tile; K = 128 is fewer K tiles than the ring has stages)."""
     from cryovit_amd._lib import EPI_RESID_HL
     from cryovit_amd.engine import ops
 
