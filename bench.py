@@ -368,7 +368,7 @@ class BoardSampler:
 
         import torch
 
-        self.hw, self.mhz, self.watts, self.on = None, [], [], False
+        self.hw, self.mhz, self.watts, self.on, self.elapsed_s, self._t0 = None, [], [], False, None, None
         try:
             pr = torch.cuda.get_device_properties(dev_index)
             want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
@@ -401,11 +401,13 @@ class BoardSampler:
             time.sleep(0.05)
 
     def start(self) -> None:
+        self._t0 = time.perf_counter()
         if self.hw:
             self.on = True
             self._thread.start()
 
     def stop(self) -> dict:
+        self.elapsed_s = time.perf_counter() - self._t0 if self._t0 else None
         if self.on:
             self.on = False
             self._thread.join()
@@ -417,6 +419,7 @@ class BoardSampler:
         return {"sclk_mhz_median": mhz, "sclk_mhz_min": min(self.mhz) if self.mhz else None, "power_w_median": med(self.watts),
                 "samples": len(self.mhz), "nominal_sclk_mhz": 2400,
                 "mfma_peak_at_held_clock_tflops": PEAK_BF16_TFLOPS * mhz / 2400.0 if mhz else None,
+                "energy_j": (med(self.watts) * self.elapsed_s) if (self.watts and self.elapsed_s) else None,
                 "note": "amdgpu sysfs over the timed region; the board holds its power limit by lowering the clock under MFMA load "
                         "(MFMA-only loops on normal(0,1) bf16 operands sustain 1.77-1.85 PFLOP/s on these boards: profiles/r03_mfma_power.txt)"}
 
@@ -640,11 +643,20 @@ def main() -> None:
                          "launches_timed": n_launch, "avg_launch_ms": k_ms, "flops_per_launch": k_flops},
             "board": board_stats,
         }
+        if board_stats.get("energy_j"):  # board energy over the timed region (median power x its wall time), this rank's GPU
+            line["board"]["joules_per_tomogram"] = board_stats["energy_j"] / args.steps
+            line["board"]["voxels_per_joule"] = args.steps * voxels / board_stats["energy_j"]
         if per_rank is not None:
             line["per_rank_voxels_per_s"] = per_rank
         if not args.no_stages:
             st = stage_breakdown(vit, head, vols[0], labels, feats_cl, feats_f16, sb)
             line["stages_ms"] = st
+            # algorithmic TFLOP/s of the five stages that hold 99 % of the FLOPs (same accounting as VitEngine.flops, SURVEY s.8d)
+            nt_, C_, Hd_, L_ = hp * wp + 1 + cfg.n_reg, cfg.dim, cfg.ffn_hidden, cfg.depth
+            toks = D_ * nt_ * L_
+            st_fl = {"gemm_qkv": 2.0 * toks * 3 * C_ * C_, "attention": 4.0 * toks * nt_ * C_, "gemm_proj": 2.0 * toks * C_ * C_,
+                     "gemm_w12": 2.0 * toks * 2 * C_ * Hd_, "gemm_w3": 2.0 * toks * Hd_ * C_}
+            line["stages_tflops"] = {k: round(v / st[k] / 1e9, 1) for k, v in st_fl.items() if st.get(k)}
             head_bytes = 402.65e6 + 134.2e6 + 33.6e6 + 16.8e6  # SURVEY s.8d: compulsory HBM bytes of configs[2]
             line["configs"] = {
                 "configs[1] ViT-g features, one tomogram": {"ms": st["vit_ms"], "voxels_per_s": voxels / st["vit_ms"] * 1e3,
