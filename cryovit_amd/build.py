@@ -58,8 +58,10 @@ ABLATION_LIB = PKG / "libcryovit_hip_ablation.so"
 def build_library(force: bool = False, verbose: bool = False, ablation: bool = False) -> Path:
     lib, build_dir = (ABLATION_LIB, PKG / "build_ablation") if ablation else (LIB, BUILD_DIR)
     extra = ["-DCVX_ABLATION"] if ablation else []
+    more = os.environ.get("CVX_EXTRA_DEFINES", "").split() if ablation else []  # experiments on the ablation build only (tools/)
+    extra += more
     stamp = build_dir / "fingerprint"
-    fp = _fingerprint() + ("+ablation" if ablation else "")
+    fp = _fingerprint() + ("+ablation" + "".join(more) if ablation else "")
     if not force and lib.exists() and stamp.exists() and stamp.read_text() == fp:
         return lib
     build_dir.mkdir(exist_ok=True)

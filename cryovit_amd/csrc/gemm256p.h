@@ -221,6 +221,18 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
     auto mma = [&](const bf16x8 (&r)[2][2], int a0, int b0, auto zero_tag) {
         constexpr bool ZERO = decltype(zero_tag)::value;
         __builtin_amdgcn_s_setprio(1);
+#if !defined(CVX_MMA_ORDER_AB)
+        // issue order: the L-side fragment is the operand kept across consecutive MFMAs (b outer, a inner).  Against the order that
+        // keeps the R-side fragment for four MFMAs (a outer, b inner: -DCVX_MMA_ORDER_AB) this is +0.3 ... +0.9 % on every ViT-g GEMM
+        // in alternating runs on one board (profiles/r03_mma_order.txt); a boustrophedon order measured the same as this one
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[a0 + a][b0 + b] = mfma16x16x32<F16>(r[a][ks], lf[b][ks], (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[a0 + a][b0 + b]);
+#else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -228,6 +240,7 @@ __device__ __forceinline__ void gemm256p_body(const uint16_t* __restrict__ Rmat,
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     acc[a0 + a][b0 + b] = mfma16x16x32<F16>(r[a][ks], lf[b][ks], (ZERO && ks == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[a0 + a][b0 + b]);
+#endif
         __builtin_amdgcn_s_setprio(0);
     };
 

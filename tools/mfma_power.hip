@@ -95,6 +95,44 @@ __global__ __launch_bounds__(256) void k_mfma(const uint4* __restrict__ src, flo
     }
 }
 
+// Issue order of the 16 MFMAs of a k-step over a 4 x 4 block of accumulators: ORDER 0 keeps the A operand for four consecutive
+// MFMAs (the GEMM tile's order), 1 keeps the B operand, 2 changes both on every instruction (diagonals)
+template <int ORDER>
+__global__ __launch_bounds__(256) void k_mfma_order(const uint4* __restrict__ src, float* __restrict__ sink, int reps) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8, src[(size_t)gid * 8 + i]);
+        b[i] = __builtin_bit_cast(bf16x8, src[(size_t)gid * 8 + 4 + i]);
+    }
+    float tot = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < 48; ++k) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = ORDER == 0 ? u : ORDER == 1 ? v : v, j = ORDER == 0 ? v : ORDER == 1 ? u : (u + v) & 3;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            asm volatile("" : "+v"(a[0]), "+v"(b[0]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tot += acc[i][j][0] + acc[i][j][3];
+    }
+    if (tot == 123.456f) sink[gid] = tot;
+}
+
 // The same MFMA work fed from LDS the way a GEMM wave tile is: per k-step of 32 a wave reads TM A fragments and TN B
 // fragments (ds_read_b128, conflict-free) and issues TM x TN MFMAs 16x16x32 -- wave tile (16 TM) x (16 TN).  NWAVES waves per
 // workgroup, one workgroup per CU.  (8, 4) x 8 waves is the shipped 256x256 tile's wave layout.  The 4-wave cases (one wave
@@ -274,6 +312,49 @@ int main() {
                    flops / (ms * 1e-3) / 1e12, median(sm.mhz), median(sm.watts), (int)sm.mhz.size());
             fflush(stdout);
         }
+    // issue order (normal data, pattern 3 still in src? -- refill)
+    {
+        uint64_t st = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&] { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+        for (auto& h : host) {
+            float g = 0.f;
+            for (int t = 0; t < 12; ++t) g += (float)((rnd() >> 11) * (1.0 / 9007199254740992.0));
+            h = bf16_of(g - 6.f);
+        }
+        CK(hipMemcpy(src, host.data(), nthreads * 128, hipMemcpyHostToDevice));
+        const char* onames[] = {"A kept for 4 MFMAs", "B kept for 4 MFMAs", "both change every MFMA"};
+        for (int rep2 = 0; rep2 < 2; ++rep2)
+        for (int order = 0; order < 3; ++order) {
+            const int reps = 200;
+            auto launch = [&] {
+                if (order == 0) hipLaunchKernelGGL(k_mfma_order<0>, dim3(blocks), dim3(256), 0, 0, src, sink, reps);
+                else if (order == 1) hipLaunchKernelGGL(k_mfma_order<1>, dim3(blocks), dim3(256), 0, 0, src, sink, reps);
+                else hipLaunchKernelGGL(k_mfma_order<2>, dim3(blocks), dim3(256), 0, 0, src, sink, reps);
+            };
+            launch();
+            CK(hipDeviceSynchronize());
+            sm.mhz.clear(); sm.watts.clear();
+            const auto t0 = std::chrono::steady_clock::now();
+            int launches = 0;
+            bool armed = false;
+            CK(hipEventRecord(e0, 0));
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5) {
+                for (int i = 0; i < 10; ++i) launch();
+                launches += 10;
+                CK(hipDeviceSynchronize());
+                if (!armed && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.5) { sm.on = true; armed = true; }
+            }
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            sm.on = false;
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double flops = (double)blocks * 4 * reps * (2.0 * 64 * 64 * 1536) * launches;
+            printf("mfma 16x16x32 normal data, order: %-24s %8.1f TFLOP/s | sclk %6.0f MHz | %6.0f W\n", onames[order], flops / (ms * 1e-3) / 1e12,
+                   median(sm.mhz), median(sm.watts));
+            fflush(stdout);
+        }
+    }
     // LDS-fed wave tiles
     {
         uint4* lsrc;
