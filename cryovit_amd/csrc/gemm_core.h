@@ -208,11 +208,20 @@ __device__ __forceinline__ void gemm_tile_body(const LoaderR& ldr, const LoaderL
             for (int a = 0; a < FR; ++a) rf[a] = *(const bf16x8*)(cur + ((offR + a * 2048) ^ (ks << 6)));
 #pragma unroll
             for (int b = 0; b < FL; ++b) lf[b] = *(const bf16x8*)(cur + ((offL + b * 2048) ^ (ks << 6)));
+            // (issue order: the B operand -- the L-side fragment -- is the one kept across consecutive MFMAs; see gemm256p.h)
+#ifndef CVX_MMA_ORDER_AB
+#pragma unroll
+            for (int b = 0; b < FL; ++b)
+#pragma unroll
+                for (int a = 0; a < FR; ++a)
+                    acc[a][b] = mfma16x16x32<epi_is_f16<Epi>::value>(rf[a], lf[b], acc[a][b]);
+#else
 #pragma unroll
             for (int a = 0; a < FR; ++a)
 #pragma unroll
                 for (int b = 0; b < FL; ++b)
                     acc[a][b] = mfma16x16x32<epi_is_f16<Epi>::value>(rf[a], lf[b], acc[a][b]);
+#endif
         }
     };
     if constexpr (Cfg::STAGES > 2) {
