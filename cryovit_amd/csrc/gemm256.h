@@ -159,9 +159,9 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int a = 0; a < 4; ++a)
                     acc[a][b0 + b] = mfma16x16x32<epi_is_f16<Epi>::value>(a < 2 ? rlo[a][ks] : rhi[a - 2][ks], lf[b][ks], acc[a][b0 + b]);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -215,9 +215,9 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 4; ++b)  // (B operand kept across consecutive MFMAs: gemm256p.h)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int a = 0; a < 2; ++a)
                     acc[a0 + a][b0 + b] = mfma16x16x32<epi_is_f16<Epi>::value>(r[a][ks], lf[b][ks], acc[a0 + a][b0 + b]);
         __builtin_amdgcn_s_setprio(0);
     };
@@ -334,9 +334,9 @@ __device__ __forceinline__ void gemm256_body(const uint16_t* __restrict__ Rmat, 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 4; ++b)  // (B operand kept across consecutive MFMAs: gemm256p.h)
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int a = 0; a < 2; ++a)
                     acc[a0 + a][b0 + b] = mfma16x16x32<epi_is_f16<Epi>::value>(r[a][ks], lf[b][ks], acc[a0 + a][b0 + b]);
         __builtin_amdgcn_s_setprio(0);
     };
