@@ -41,7 +41,12 @@ const char* cvx_last_error(void);
 int cvx_version(void);
 /* name of the device the library would launch on ("gfx950...") or "" when no HIP device is visible */
 int cvx_device_arch(char* buf, int buflen);
-/* tuning switches for in-process A/B measurements: "use_gemm256" (0/1), "gemm256_variant" (pipeline schedule id) */
+/* Process-global tuning switches for in-process A/B measurements (tools/, tests): every default is the shipped, measured-best setting and
+ * no product path sets one.  Returns non-zero (cvx_last_error) for an unknown name or a value the library was not built with (the product
+ * library holds the shipped kernel variants only; the rejected ones live in the -DCVX_ABLATION build).  Names: use_gemm256, gemm256_variant,
+ * gemm_stagger, gemm_tail_split, gemm_tail_max, gemm_tail_tile, gemm_tail_deep, gemm_resid_reverse, gemm_resid_stagger, tile_group_l,
+ * attn_variant, attn_xcd_remap, attn_mfma_prio, attn_half_tile, win_attn_prefetch, win_attn_x32, conv_halo, conv_wide, convt_small,
+ * ln_policy -- each is described where it is defined (csrc/gemm.hip, attention.hip, hiera.hip) and in DESIGN.md s.4 / s.8. */
 int cvx_set_option(const char* name, int value);
 /* diagnostic: per-wave cycle sums {load, load-barrier, mma, mma-barrier} x 8 waves written by gemm256 variant 20 */
 int cvx_debug_read_gemm256(unsigned long long* out32);
