@@ -376,7 +376,7 @@ class BoardSampler:
                 if want in os.path.realpath(d):
                     hw = sorted(glob.glob(d + "/hwmon/hwmon*"))
                     self.hw = hw[0] if hw else None
-        except (AttributeError, OSError, RuntimeError) as e:  # a missing attribute or an unreadable sysfs only drops the optional fields
+        except (AttributeError, AssertionError, OSError, RuntimeError) as e:  # no device / a missing attribute / an unreadable sysfs only drops the optional fields
             print(f"[bench] board sampler off: {e}", file=sys.stderr)
             self.hw = None
         self._thread = threading.Thread(target=self._run, daemon=True)

@@ -56,3 +56,18 @@ def test_failing_rank_fails_the_run():
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_board_sampler_without_a_device():
+    """The clock / power sampler of the bench line is optional evidence: without a card (or without readable sysfs files) every
+    field is None and nothing raises."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    b = bench.BoardSampler(0)
+    b.start()
+    st = b.stop()
+    assert st["sclk_mhz_median"] is None and st["power_w_median"] is None and st["samples"] == 0 and st["energy_j"] is None
